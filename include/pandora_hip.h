@@ -1,0 +1,180 @@
+/*
+ * pandora_hip.h -- C ABI of libpandora_hip.so, the MI355X (gfx950) implementation of Pandora's
+ * ray-traversal hot path. This is the only way host code reaches the GPU.
+ *
+ * The reference (mathijs727/pandora) has no FFI layer; its seam is the C++ interface
+ *     AccelerationStructure<HitRayState, AnyHitRayState>::intersect / intersectAny
+ *         projects/pandora/include/pandora/traversal/acceleration_structure.h:6-11
+ * implemented by OfflineBatchingAccelerationStructure (+Builder)
+ *         projects/pandora/include/pandora/traversal/offline_batching_acceleration_structure.h:30-126
+ * The header-only adapter include/pandora_amd/gpu_acceleration_structure.hpp keeps that interface
+ * and is the intended caller of everything below. Each entry point names what it replaces.
+ *
+ * Conventions: every function returns PGPU_OK (0) or a negative PGPU_ERR_* code and never throws
+ * (the reference reports errors by C++ exceptions, utility/error_handling.h:7-37);
+ * pgpu_last_error() returns a human-readable message for the last failure on that context.
+ * All pointers are plain host pointers unless a parameter says "device". No torch types.
+ */
+#ifndef PANDORA_HIP_H
+#define PANDORA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    PGPU_OK = 0,
+    PGPU_ERR_INVALID = -1,     /* bad argument (null pointer, out-of-range id, size mismatch) */
+    PGPU_ERR_HIP = -2,         /* a HIP runtime call failed; see pgpu_last_error */
+    PGPU_ERR_SINGLE_LEAF = -3, /* top level needs >= 2 batching points (pauseable_bvh4.h:180) */
+    PGPU_ERR_DEPTH = -4,       /* tree deeper than the traversal stacks allow */
+    PGPU_ERR_NO_SCENE = -5,    /* trace called before the structure it needs was uploaded */
+    PGPU_ERR_NO_DEVICE = -6
+};
+
+enum { PGPU_CLOSEST = 0, PGPU_ANY = 1 };           /* intersect / intersectAny */
+enum { PGPU_TRI_MT = 0, PGPU_TRI_WATERTIGHT = 1 }; /* triangle_intersect.cpp:425-462 / :340-423 */
+enum { PGPU_MEM_HOST = 0, PGPU_MEM_DEVICE = 1 };   /* where ray / hit arrays live */
+#define PGPU_MISS 0xFFFFFFFFu
+#define PGPU_NO_SVDAG 0xFFFFFFFFu
+
+typedef struct pgpu_ctx pgpu_ctx;
+
+/* ------------------------------------------------------------------ host-side construction
+ * Replaces the rtcBuildBVH calls of wive_bvh8_build8_impl.h:87-104 (bottom level) and
+ * pauseable_bvh4.h:160-176 (top level) and the scene cut of batching.cpp:38-265. Output arrays are
+ * in the reference's layouts: 256-byte nodes (wive_bvh8.h:76-86), u32 leaf-index array and 3+29 bit
+ * handles (wive_bvh8_impl.h:333-382); 112-byte nodes (pauseable_bvh4.h:74-98). No GPU needed. */
+typedef struct pgpu_host_bvh8 pgpu_host_bvh8;
+typedef struct pgpu_host_bvh4 pgpu_host_bvh4;
+
+/* BVH8 over the triangles prim_ids[0..n_prims) of an indexed mesh (prim_ids NULL = all of them,
+ * n_prims = n_triangles). Leaf object j is triangle prim_ids[j]. max_leaf in 1..4. */
+int pgpu_build_bvh8(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* prim_ids, size_t n_prims, uint32_t max_leaf, pgpu_host_bvh8** out);
+const void* pgpu_host_bvh8_nodes(const pgpu_host_bvh8*, size_t* n_nodes);
+const uint32_t* pgpu_host_bvh8_leaf_indices(const pgpu_host_bvh8*, size_t* n_indices);
+uint32_t pgpu_host_bvh8_root(const pgpu_host_bvh8*);
+int pgpu_host_bvh8_depth(const pgpu_host_bvh8*); /* nested inner nodes on the longest path */
+void pgpu_host_bvh8_free(pgpu_host_bvh8*);
+
+/* BVH4 over batching-point bounds (n_leaves x {min xyz, max xyz}); leaf_order[k] = input leaf stored
+ * at final leaf slot k (the reference moves leaves into m_leafs in this order, :461-467). */
+int pgpu_build_top_bvh4(const float* leaf_bounds, size_t n_leaves, pgpu_host_bvh4** out);
+const void* pgpu_host_bvh4_nodes(const pgpu_host_bvh4*, size_t* n_nodes);
+const uint32_t* pgpu_host_bvh4_leaf_order(const pgpu_host_bvh4*, size_t* n_leaves);
+uint32_t pgpu_host_bvh4_root(const pgpu_host_bvh4*);
+int pgpu_host_bvh4_depth(const pgpu_host_bvh4*);
+void pgpu_host_bvh4_free(pgpu_host_bvh4*);
+
+/* Groups triangles into batching points of <= max_prims primitives (primitivesPerBatchingPoint). */
+int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    size_t max_prims, uint32_t* group_of_prim, uint32_t* n_groups);
+
+/* Voxelises each group of triangles into a resolution^3 grid over the group's bounds
+ * (TriangleShape::voxelize, triangle_intersect.cpp:224-329), builds one SVO per group
+ * (sparse_voxel_dag.cpp:39-133) and merges them into one shared DAG array (compressDAGs, :135-226).
+ * group_prims/group_offsets: CSR lists of triangle ids per group. */
+typedef struct {
+    uint32_t root;         /* m_rootNodeOffset into the shared array */
+    float bounds_min[3];   /* m_boundsMin */
+    float inv_extent;      /* m_invBoundsExtent (all three components equal) */
+    uint32_t resolution;
+} pgpu_svdag_desc;
+typedef struct pgpu_host_svdags pgpu_host_svdags;
+int pgpu_build_svdags(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t resolution,
+    pgpu_host_svdags** out);
+const uint32_t* pgpu_host_svdags_words(const pgpu_host_svdags*, size_t* n_words);
+const pgpu_svdag_desc* pgpu_host_svdags_descs(const pgpu_host_svdags*, size_t* n_dags);
+size_t pgpu_host_svdags_words_before_compression(const pgpu_host_svdags*);
+void pgpu_host_svdags_free(pgpu_host_svdags*);
+/* Expands DAG `dag` back into a dense bit grid (z-major, x fastest, 1 bit per voxel packed LSB first
+ * in u32 words, same addressing as VoxelGrid::index, voxel_grid.cpp:149-159). For validation. */
+int pgpu_svdag_expand(const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dag, uint32_t* grid_bits);
+int pgpu_voxelize(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* prims, size_t n_prims, uint32_t resolution, float bounds_out[6], uint32_t* grid_bits);
+
+/* ------------------------------------------------------------------ device context
+ * One context per GPU, one process per GPU. Replaces the TaskGraph/LRU-cache plumbing the reference
+ * threads through its builder (offline_batching_acceleration_structure.h:106-126). */
+int pgpu_init(int device_id, pgpu_ctx** out);
+void pgpu_shutdown(pgpu_ctx*);
+const char* pgpu_last_error(const pgpu_ctx*);
+const char* pgpu_version(void);
+
+/* Geometry of one shape: indexed triangles, TriangleShape m_positions / m_indices (triangle.h:78-87). */
+int pgpu_upload_mesh(pgpu_ctx*, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    uint32_t* mesh_id);
+
+/* One bottom-level BVH8 in the reference layout (what CachedBVH deserialises, offline_bvh_cache.cpp:138-148)
+ * plus its leaf-object table: leaf object j is primitive objs[j].prim of mesh objs[j].mesh
+ * (OfflineBVHLeaf::Primitive, offline_bvh_cache.h:18-39). */
+typedef struct {
+    uint32_t mesh;
+    uint32_t prim;
+} pgpu_leafobj;
+int pgpu_upload_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
+
+/* Shared SVDAG array + one descriptor per DAG (SparseVoxelDAG members, sparse_voxel_dag.h:70-78). */
+int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags);
+
+/* Top-level PauseableBVH4 (m_bvhNodes, m_leafs, m_rootHandle; pauseable_bvh4.h:100-103). Leaf k is a
+ * batching point: its bottom-level BVH and its SVDAG (PGPU_NO_SVDAG = none, i.e. svdagRes 0). */
+typedef struct {
+    uint32_t bvh_id;
+    uint32_t svdag;
+} pgpu_leaf;
+int pgpu_upload_top_bvh4(pgpu_ctx*, const void* nodes112, size_t n_nodes, uint32_t root, const pgpu_leaf* leaves, size_t n_leaves);
+
+/* ------------------------------------------------------------------ tracing
+ * SoA ray batch: Ray{origin, direction, tnear, tfar} of graphics_core/ray.h:14-40. */
+typedef struct {
+    const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar;
+} pgpu_rays;
+/* Closest-hit result per ray: t = final ray.tfar (the input tfar on a miss), obj = leaf-object index
+ * inside the BVH8 that was hit or PGPU_MISS, leaf = top-level leaf (0 for single level), u,v =
+ * RayHit::geometricUV. visits (may be NULL) = Ray::numTopLevelIntersections. */
+typedef struct {
+    float* t;
+    uint32_t* obj;
+    uint32_t* leaf;
+    float *u, *v;
+    uint32_t* visits;
+} pgpu_hits;
+typedef struct {
+    uint64_t svdag_tests, svdag_culled; /* g_stats.svdag.numIntersectionTests / numRaysCulled */
+    uint64_t leaf_visits;               /* rays parked at batching points, summed */
+    uint64_t rounds;                    /* wavefront rounds the two-level loop needed */
+    uint64_t inner_visits, leaf_pops, tri_tests; /* filled only when stats are enabled */
+} pgpu_counters;
+
+/* WiVeBVH8::intersect / intersectAny over a batch (wive_bvh8_impl.h:57-201): single-level, in-core.
+ * kind PGPU_CLOSEST fills `hits`; PGPU_ANY fills any_hit[i] = 0/1. mem says where the ray and result
+ * arrays live; stream is a hipStream_t (NULL = the context's own stream; device arrays only). */
+int pgpu_trace_bvh8(pgpu_ctx*, uint32_t bvh_id, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
+    const pgpu_hits* hits, uint32_t* any_hit, void* stream);
+
+/* OfflineBatchingAccelerationStructure::intersect / intersectAny (offline_batching...h:406-437)
+ * driven to completion for the whole batch: top-level traversal, SVDAG early-out, parking at batching
+ * points, per-leaf bottom-level traversal, resume -- until every ray has exited. */
+int pgpu_trace(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
+    const pgpu_hits* hits, uint32_t* any_hit, pgpu_counters* counters, void* stream);
+
+/* Diagnostics: device time of the traversal kernels of the last trace call on this context, measured
+ * with HIP events on the stream they ran on (ms); enables/disables visit counters. */
+float pgpu_last_kernel_ms(const pgpu_ctx*);
+/* Waits for the traces issued with PGPU_MEM_DEVICE on `stream` (NULL = the context's stream) and
+ * refreshes pgpu_last_kernel_ms / pgpu_get_counters. Host-memory traces are synchronous already. */
+int pgpu_sync(pgpu_ctx*, void* stream);
+int pgpu_set_stats(pgpu_ctx*, int enabled);
+int pgpu_get_counters(pgpu_ctx*, pgpu_counters* out);
+int pgpu_set_tuning(pgpu_ctx*, int blocks_per_cu, int chunk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,150 @@
+/*
+ * pandora_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar CPU restatement of the reference's ray-traversal hot path (mathijs727/pandora).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (pandora_amd/, include/) never links, loads or calls it.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - SIMD primitive semantics (x86 min/max NaN rule, permute, compress, horizontalMinIndex,
+ *     bitScan4, bitScanReverse32): pinned against the reference's own simd headers compiled
+ *     from /root/reference into oracle/_ref (oracle/ref_simd_harness.cpp) and against the
+ *     known-answer values of projects/simd/tests/src/test_simd{4,8}.cpp (tests/golden/simd_kat.json).
+ *   - Moller-Trumbore leaf test: pinned by the known-answer rays of
+ *     projects/pandora/tests/test_triangle.cpp:12-64 (tests/golden/triangle_kat.json).
+ *   - Traversal control flow (BVH8 / BVH4 / SVDAG loops): PARITY UNPINNED by reference tests
+ *     (the reference has none) and the reference traversal headers cannot be built
+ *     here without writing stand-ins for EASTL/flatbuffers/Embree/mio/glm, so they are treated as
+ *     unbuildable. The loops are restated from source and cross-checked against a second,
+ *     independently written restatement that runs on the reference's simd library (oracle/_ref).
+ *
+ * All arithmetic is IEEE binary32 with contraction OFF (-ffp-contract=off), matching the kernels.
+ */
+#ifndef PANDORA_ORACLE_H
+#define PANDORA_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MISS 0xFFFFFFFFu
+
+/* wive_bvh8.h:76-86 -- 256-byte node, on-disk layout verbatim */
+typedef struct {
+    float minX[8], maxX[8], minY[8], maxY[8], minZ[8], maxZ[8];
+    uint32_t children[8];
+    uint32_t perm[8];
+} orc_bvh8_node;
+
+/* pauseable_bvh4.h:74-98 -- 112-byte node; bits = validMask:4 | leafMask:4<<4 | depth:8<<8 */
+typedef struct {
+    float minX[4], minY[4], minZ[4], maxX[4], maxY[4], maxZ[4];
+    uint32_t firstChild, firstLeaf, parent, bits;
+} orc_bvh4_node;
+
+typedef struct {
+    float o[3], d[3], tnear, tfar;
+} orc_ray;
+
+typedef struct {
+    float t;       /* final ray.tfar (input tfar when missed)            */
+    uint32_t obj;  /* leaf-object index inside the BVH8, ORC_MISS = miss */
+    uint32_t leaf; /* top-level leaf (batching point) index, 0 if single level */
+    float u, v;
+} orc_hit;
+
+/* indexed triangle mesh, triangle.h:78-87 */
+typedef struct {
+    const float* pos;    /* nv*3 */
+    const uint32_t* idx; /* nt*3 */
+} orc_mesh;
+
+/* one bottom-level BVH8 over leaf objects; leaf object j = triangle obj_prim[j] of mesh */
+typedef struct {
+    const orc_bvh8_node* nodes;
+    const uint32_t* leaf_idx;
+    uint32_t root;
+    const uint32_t* obj_prim; /* n_objs, may be NULL (identity) */
+    orc_mesh mesh;
+} orc_bvh8;
+
+/* sparse_voxel_dag.h:70-78 */
+typedef struct {
+    const uint32_t* data; /* shared node array */
+    uint32_t root;        /* m_rootNodeOffset */
+    float bounds_min[3];
+    float inv_extent; /* 1 / max extent, splat */
+    int enabled;
+} orc_svdag;
+
+typedef struct {
+    orc_bvh8 bvh;
+    orc_svdag dag;
+} orc_leaf;
+
+typedef struct {
+    const orc_bvh4_node* nodes;
+    uint32_t root;
+    const orc_leaf* leaves;
+    uint32_t n_leaves;
+} orc_scene;
+
+typedef struct {
+    uint64_t svdag_tests, svdag_culled; /* g_stats.svdag.* (offline_batching...h:275-279) */
+    uint64_t leaf_visits;               /* sum of ray.numTopLevelIntersections */
+    uint64_t inner_visits, leaf_pops, tri_tests; /* traffic model */
+} orc_counters;
+
+enum { ORC_TRI_MT = 0, ORC_TRI_WATERTIGHT = 1 };
+
+/* triangle_intersect.cpp:425-462 (MT, active) / :340-423 (watertight, #if 0). Returns 1 on hit and
+ * shortens *tfar; u,v = geometricUV. */
+int orc_tri_intersect(int mode, const float o[3], const float d[3], float tnear, float* tfar,
+    const float p0[3], const float p1[3], const float p2[3], float* u, float* v);
+
+/* simd primitive restatements (S4) */
+void orc_compress_perm8(unsigned mask, uint32_t out[8]);   /* simd8_avx2.ipp:1-17,103-118 */
+unsigned orc_hmin_index4(const float v[4]);                /* simd4_avx2.ipp:412-430 */
+int orc_bitscan4(unsigned mask);                           /* intrinsics.h:22-34 */
+int orc_bsr32(uint32_t mask);                              /* intrinsics.h:93-126 */
+uint32_t orc_sign_shift(float dx, float dy, float dz);     /* wive_bvh8_impl.h:384-388 */
+/* wive_bvh8_build8_impl.h:172-203: octant permutation words for one node's child boxes */
+void orc_bvh8_perm(const float lo[][3], const float hi[][3], unsigned n_children, uint32_t perm[8]);
+
+/* wive_bvh8_impl.h:209-238 */
+unsigned orc_bvh8_inner(const orc_bvh8_node* n, const orc_ray* r, uint32_t out_children[8], float out_dist[8]);
+
+/* wive_bvh8_impl.h:57-140 / :142-201. Ray tfar is updated like the reference (closest: hit t; any: -inf). */
+int orc_bvh8_intersect(const orc_bvh8* b, int tri_mode, orc_ray* r, orc_hit* h, orc_counters* c);
+int orc_bvh8_intersect_any(const orc_bvh8* b, int tri_mode, orc_ray* r, orc_counters* c);
+
+/* sparse_voxel_dag.cpp:350-567; lanes = 4 (faithful, incl. the lane-3 artefact) or 3 */
+int orc_svdag_intersect(const orc_svdag* d, const orc_ray* r, int lanes);
+
+/* pauseable_bvh4.h:225-355 driven to completion per ray: every pause is followed immediately by the
+ * leaf's bottom-level traversal and a resume (offline_batching...h:179-205, :226-259). */
+int orc_scene_intersect(const orc_scene* s, int tri_mode, int svdag_lanes, orc_ray* r, orc_hit* h, orc_counters* c);
+int orc_scene_intersect_any(const orc_scene* s, int tri_mode, int svdag_lanes, orc_ray* r, orc_counters* c);
+
+/* one top-level episode: runs until the ray pauses at a leaf (returns 1, leaf, node and stack are set)
+ * or exits (returns 0). Used to check the per-visit tokens the GPU emits. */
+int orc_bvh4_step(const orc_scene* s, int any_hit, int svdag_lanes, const orc_ray* r,
+    uint32_t* node, uint64_t* stack, uint32_t* leaf, orc_counters* c);
+
+/* batch drivers (SoA rays [8][n]: ox,oy,oz,dx,dy,dz,tnear,tfar), n_threads >= 1 */
+void orc_bvh8_trace(const orc_bvh8* b, int any_hit, int tri_mode, const float* rays, size_t n,
+    float* t, uint32_t* obj, float* u, float* v, uint32_t* anyhit, orc_counters* c, int n_threads);
+void orc_scene_trace(const orc_scene* s, int any_hit, int tri_mode, int svdag_lanes, const float* rays, size_t n,
+    float* t, uint32_t* obj, uint32_t* leaf, float* u, float* v, uint32_t* anyhit, uint32_t* visits,
+    orc_counters* c, int n_threads);
+
+/* brute force over all triangles with the same leaf test; independent of any tree */
+void orc_brute_trace(const orc_mesh* m, size_t n_tris, int tri_mode, const float* rays, size_t n,
+    float* t, uint32_t* prim, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,274 @@
+"""Host-side driver over the C ABI, used by the tests and bench.py.
+
+Mirrors the reference's builder -> acceleration-structure flow
+(OfflineBatchingAccelerationStructureBuilder::build and ::intersect / ::intersectAny,
+projects/pandora/include/pandora/traversal/offline_batching_acceleration_structure.h:106-126,406-437)
+for ray *batches*: the per-ray interface with hit/miss callbacks lives in the C++ adapter
+include/pandora_amd/gpu_acceleration_structure.hpp; this module is the thin Python equivalent.
+All computation happens in libpandora_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+from .capi import PandoraError
+
+
+def _check(rc: int, ctx=None, what: str = ""):
+    if rc != capi.OK:
+        msg = capi.lib().pgpu_last_error(ctx).decode() if ctx else what
+        raise PandoraError(rc, msg or what)
+
+
+@dataclass
+class HostBvh8:
+    """Bottom-level BVH8 in the reference's on-disk layout (wive_bvh8.fbs + contiguous_allocator.fbs)."""
+    nodes: np.ndarray      # (n_nodes, 64) float32 view of 256-byte nodes
+    leaf_idx: np.ndarray   # uint32
+    root: int
+    depth: int
+    prim_ids: np.ndarray   # leaf object j -> triangle id in the mesh
+
+    @property
+    def n_nodes(self) -> int:
+        return int(self.nodes.shape[0])
+
+    def scene_bytes(self, n_verts: int) -> int:
+        return 256 * self.n_nodes + 4 * self.leaf_idx.size + 12 * self.prim_ids.size + 12 * n_verts
+
+
+def build_bvh8(pos: np.ndarray, idx: np.ndarray, prim_ids: np.ndarray | None = None, max_leaf: int = 4) -> HostBvh8:
+    L = capi.lib()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    if prim_ids is None:
+        prim_ids = np.arange(idx.shape[0], dtype=np.uint32)
+    prim_ids = np.ascontiguousarray(prim_ids, np.uint32)
+    h = C.c_void_p()
+    _check(L.pgpu_build_bvh8(pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prim_ids.ctypes.data, prim_ids.size, max_leaf, C.byref(h)),
+           what="pgpu_build_bvh8 failed")
+    try:
+        n = C.c_size_t()
+        p = L.pgpu_host_bvh8_nodes(h, C.byref(n))
+        nodes = capi.view(p, n.value * 64, np.float32).reshape(-1, 64).copy() if n.value else np.zeros((0, 64), np.float32)
+        p = L.pgpu_host_bvh8_leaf_indices(h, C.byref(n))
+        leaf_idx = capi.view(p, n.value, np.uint32).copy()
+        return HostBvh8(nodes, leaf_idx, int(L.pgpu_host_bvh8_root(h)), int(L.pgpu_host_bvh8_depth(h)), prim_ids)
+    finally:
+        L.pgpu_host_bvh8_free(h)
+
+
+@dataclass
+class HostBvh4:
+    nodes: np.ndarray       # (n_nodes, 28) float32 view of 112-byte nodes
+    leaf_order: np.ndarray  # final leaf slot -> input leaf
+    root: int
+    depth: int
+
+
+def build_top_bvh4(leaf_bounds: np.ndarray) -> HostBvh4:
+    L = capi.lib()
+    b = np.ascontiguousarray(leaf_bounds, np.float32).reshape(-1, 6)
+    h = C.c_void_p()
+    _check(L.pgpu_build_top_bvh4(b.ctypes.data, b.shape[0], C.byref(h)), what="pgpu_build_top_bvh4 failed")
+    try:
+        n = C.c_size_t()
+        p = L.pgpu_host_bvh4_nodes(h, C.byref(n))
+        nodes = capi.view(p, n.value * 28, np.float32).reshape(-1, 28).copy()
+        p = L.pgpu_host_bvh4_leaf_order(h, C.byref(n))
+        order = capi.view(p, n.value, np.uint32).copy()
+        return HostBvh4(nodes, order, int(L.pgpu_host_bvh4_root(h)), int(L.pgpu_host_bvh4_depth(h)))
+    finally:
+        L.pgpu_host_bvh4_free(h)
+
+
+def partition_prims(pos: np.ndarray, idx: np.ndarray, max_prims: int):
+    """-> (group_of_prim uint32[nt], n_groups)."""
+    L = capi.lib()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    out = np.empty(idx.shape[0], np.uint32)
+    ng = C.c_uint32()
+    _check(L.pgpu_partition_prims(pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], max_prims, out.ctypes.data, C.byref(ng)),
+           what="pgpu_partition_prims failed")
+    return out, int(ng.value)
+
+
+@dataclass
+class HostSvdags:
+    words: np.ndarray       # shared uint32 node array
+    descs: np.ndarray       # structured: root, bounds_min[3], inv_extent, resolution
+    words_before: int
+
+
+SVDAG_DESC_DTYPE = np.dtype([("root", np.uint32), ("bounds_min", np.float32, 3), ("inv_extent", np.float32), ("resolution", np.uint32)])
+
+
+def build_svdags(pos, idx, groups: list[np.ndarray], resolution: int) -> HostSvdags:
+    L = capi.lib()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    prims = np.ascontiguousarray(np.concatenate(groups), np.uint32)
+    offs = np.zeros(len(groups) + 1, np.uint64)
+    offs[1:] = np.cumsum([g.size for g in groups])
+    h = C.c_void_p()
+    _check(L.pgpu_build_svdags(pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prims.ctypes.data, offs.ctypes.data, len(groups), resolution, C.byref(h)),
+           what="pgpu_build_svdags failed")
+    try:
+        n = C.c_size_t()
+        p = L.pgpu_host_svdags_words(h, C.byref(n))
+        words = capi.view(p, n.value, np.uint32).copy()
+        p = L.pgpu_host_svdags_descs(h, C.byref(n))
+        descs = capi.view(p, n.value, SVDAG_DESC_DTYPE).copy()
+        return HostSvdags(words, descs, int(L.pgpu_host_svdags_words_before_compression(h)))
+    finally:
+        L.pgpu_host_svdags_free(h)
+
+
+def voxelize(pos, idx, prims, resolution: int):
+    L = capi.lib()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    prims = np.ascontiguousarray(prims, np.uint32)
+    bits = np.zeros((resolution**3 + 31) // 32, np.uint32)
+    bounds = np.zeros(6, np.float32)
+    _check(L.pgpu_voxelize(pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prims.ctypes.data, prims.size, resolution, bounds.ctypes.data, bits.ctypes.data),
+           what="pgpu_voxelize failed")
+    return bits, bounds
+
+
+def svdag_expand(words: np.ndarray, desc) -> np.ndarray:
+    L = capi.lib()
+    d = capi.SvdagDesc(int(desc["root"]), (C.c_float * 3)(*[float(x) for x in desc["bounds_min"]]), float(desc["inv_extent"]), int(desc["resolution"]))
+    res = int(desc["resolution"])
+    bits = np.zeros((res**3 + 31) // 32, np.uint32)
+    _check(L.pgpu_svdag_expand(words.ctypes.data, words.size, C.byref(d), bits.ctypes.data), what="pgpu_svdag_expand failed")
+    return bits
+
+
+class Context:
+    """One GPU context (pgpu_ctx). Ray batches are SoA float32 arrays of shape (8, n): numpy (host
+    memory, copied by the library) or torch CUDA tensors (device memory, used in place)."""
+
+    def __init__(self, device: int = 0):
+        self._L = capi.lib()
+        h = C.c_void_p()
+        rc = self._L.pgpu_init(device, C.byref(h))
+        if rc != capi.OK:
+            raise PandoraError(rc, "pgpu_init failed (no GPU visible?)")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pgpu_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene upload
+    def upload_mesh(self, pos, idx) -> int:
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+        out = C.c_uint32()
+        _check(self._L.pgpu_upload_mesh(self._h, pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], C.byref(out)), self._h)
+        return int(out.value)
+
+    def upload_bvh8(self, bvh: HostBvh8, mesh_id: int) -> int:
+        objs = np.empty((bvh.prim_ids.size, 2), np.uint32)
+        objs[:, 0] = mesh_id
+        objs[:, 1] = bvh.prim_ids
+        nodes = np.ascontiguousarray(bvh.nodes)
+        out = C.c_uint32()
+        _check(self._L.pgpu_upload_bvh8(self._h, nodes.ctypes.data, bvh.n_nodes, bvh.leaf_idx.ctypes.data, bvh.leaf_idx.size, bvh.root,
+                                        objs.ctypes.data, objs.shape[0], C.byref(out)), self._h)
+        return int(out.value)
+
+    def upload_svdags(self, dags: HostSvdags):
+        descs = np.ascontiguousarray(dags.descs)
+        _check(self._L.pgpu_upload_svdags(self._h, dags.words.ctypes.data, dags.words.size, descs.ctypes.data, descs.size), self._h)
+
+    def upload_top_bvh4(self, top: HostBvh4, leaves: np.ndarray):
+        """leaves: (n_leaves, 2) uint32 [bvh_id, svdag index or NO_SVDAG] in final leaf-slot order."""
+        leaves = np.ascontiguousarray(leaves, np.uint32).reshape(-1, 2)
+        nodes = np.ascontiguousarray(top.nodes)
+        _check(self._L.pgpu_upload_top_bvh4(self._h, nodes.ctypes.data, nodes.shape[0], top.root, leaves.ctypes.data, leaves.shape[0]), self._h)
+
+    # -- tracing
+    @staticmethod
+    def _is_torch(a) -> bool:
+        return not isinstance(a, np.ndarray)
+
+    def _rays_struct(self, rays):
+        n = int(rays.shape[1])
+        assert rays.shape[0] == 8
+        if self._is_torch(rays):
+            assert rays.is_cuda and rays.is_contiguous() and str(rays.dtype) == "torch.float32"
+            base, stride = rays.data_ptr(), n * 4
+        else:
+            assert rays.dtype == np.float32 and rays.flags["C_CONTIGUOUS"]
+            base, stride = rays.ctypes.data, n * 4
+        return capi.Rays(*[base + i * stride for i in range(8)]), n
+
+    def _alloc(self, like, n, kind):
+        if self._is_torch(like):
+            import torch
+            dt = torch.float32 if kind == "f" else torch.int32
+            return torch.empty(n, dtype=dt, device=like.device)
+        return np.empty(n, np.float32 if kind == "f" else np.uint32)
+
+    def trace_bvh8(self, bvh_id: int, rays, kind: int = capi.CLOSEST, tri_mode: int = capi.TRI_MT, out=None, stream: int = 0):
+        """Single-level trace. Returns dict(t, obj, leaf, u, v) for CLOSEST or dict(hit) for ANY."""
+        r, n = self._rays_struct(rays)
+        mem = capi.MEM_DEVICE if self._is_torch(rays) else capi.MEM_HOST
+        if kind == capi.CLOSEST:
+            if out is None:
+                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v")}
+            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), 0)
+            _check(self._L.pgpu_trace_bvh8(self._h, bvh_id, kind, tri_mode, C.byref(r), n, mem, C.byref(h), None, stream), self._h)
+        else:
+            if out is None:
+                out = {"hit": self._alloc(rays, n, "u")}
+            _check(self._L.pgpu_trace_bvh8(self._h, bvh_id, kind, tri_mode, C.byref(r), n, mem, None, capi.ptr(out["hit"]), stream), self._h)
+        return out
+
+    def trace(self, rays, kind: int = capi.CLOSEST, tri_mode: int = capi.TRI_MT, out=None, stream: int = 0):
+        """Two-level trace through the uploaded top-level BVH4. Returns (results, counters dict)."""
+        r, n = self._rays_struct(rays)
+        mem = capi.MEM_DEVICE if self._is_torch(rays) else capi.MEM_HOST
+        cnt = capi.Counters()
+        if kind == capi.CLOSEST:
+            if out is None:
+                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v", "visits")}
+            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), capi.ptr(out.get("visits")))
+            _check(self._L.pgpu_trace(self._h, kind, tri_mode, C.byref(r), n, mem, C.byref(h), None, C.byref(cnt), stream), self._h)
+        else:
+            if out is None:
+                out = {"hit": self._alloc(rays, n, "u"), "visits": self._alloc(rays, n, "u")}
+            h = capi.Hits(0, 0, 0, 0, 0, capi.ptr(out.get("visits")))
+            _check(self._L.pgpu_trace(self._h, kind, tri_mode, C.byref(r), n, mem, C.byref(h), capi.ptr(out["hit"]), C.byref(cnt), stream), self._h)
+        return out, {f: int(getattr(cnt, f)) for f, _ in capi.Counters._fields_}
+
+    def sync(self, stream: int = 0):
+        _check(self._L.pgpu_sync(self._h, stream), self._h)
+
+    def last_kernel_ms(self) -> float:
+        return float(self._L.pgpu_last_kernel_ms(self._h))
+
+    def set_stats(self, on: bool):
+        _check(self._L.pgpu_set_stats(self._h, int(on)), self._h)
+
+    def set_tuning(self, blocks_per_cu: int, chunk: int):
+        _check(self._L.pgpu_set_tuning(self._h, blocks_per_cu, chunk), self._h)
+
+    def counters(self) -> dict:
+        cnt = capi.Counters()
+        _check(self._L.pgpu_get_counters(self._h, C.byref(cnt)), self._h)
+        return {f: int(getattr(cnt, f)) for f, _ in capi.Counters._fields_}

@@ -1,0 +1,129 @@
+"""ctypes binding of libpandora_hip.so (include/pandora_hip.h). Thin: pointers and sizes only.
+
+The library must exist (run `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C pandora_amd`); there is no fallback path of any kind.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpandora_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_SINGLE_LEAF, ERR_DEPTH, ERR_NO_SCENE, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+CLOSEST, ANY = 0, 1
+TRI_MT, TRI_WATERTIGHT = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+MISS = 0xFFFFFFFF
+NO_SVDAG = 0xFFFFFFFF
+
+c_f32p = C.POINTER(C.c_float)
+c_u32p = C.POINTER(C.c_uint32)
+c_u64p = C.POINTER(C.c_uint64)
+
+
+class Rays(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ox", "oy", "oz", "dx", "dy", "dz", "tnear", "tfar")]
+
+
+class Hits(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("t", "obj", "leaf", "u", "v", "visits")]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "rounds", "inner_visits", "leaf_pops", "tri_tests")]
+
+
+class LeafObj(C.Structure):
+    _fields_ = [("mesh", C.c_uint32), ("prim", C.c_uint32)]
+
+
+class Leaf(C.Structure):
+    _fields_ = [("bvh_id", C.c_uint32), ("svdag", C.c_uint32)]
+
+
+class SvdagDesc(C.Structure):
+    _fields_ = [("root", C.c_uint32), ("bounds_min", C.c_float * 3), ("inv_extent", C.c_float), ("resolution", C.c_uint32)]
+
+
+# every symbol include/pandora_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "pgpu_build_bvh8": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "pgpu_host_bvh8_nodes": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pgpu_host_bvh8_leaf_indices": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pgpu_host_bvh8_root": (C.c_uint32, [C.c_void_p]),
+    "pgpu_host_bvh8_depth": (C.c_int, [C.c_void_p]),
+    "pgpu_host_bvh8_free": (None, [C.c_void_p]),
+    "pgpu_build_top_bvh4": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pgpu_host_bvh4_nodes": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pgpu_host_bvh4_leaf_order": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pgpu_host_bvh4_root": (C.c_uint32, [C.c_void_p]),
+    "pgpu_host_bvh4_depth": (C.c_int, [C.c_void_p]),
+    "pgpu_host_bvh4_free": (None, [C.c_void_p]),
+    "pgpu_partition_prims": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "pgpu_build_svdags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "pgpu_host_svdags_words": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pgpu_host_svdags_descs": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "pgpu_host_svdags_words_before_compression": (C.c_size_t, [C.c_void_p]),
+    "pgpu_host_svdags_free": (None, [C.c_void_p]),
+    "pgpu_svdag_expand": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(SvdagDesc), C.c_void_p]),
+    "pgpu_voxelize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pgpu_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pgpu_shutdown": (None, [C.c_void_p]),
+    "pgpu_last_error": (C.c_char_p, [C.c_void_p]),
+    "pgpu_version": (C.c_char_p, []),
+    "pgpu_upload_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pgpu_upload_bvh8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pgpu_upload_svdags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "pgpu_upload_top_bvh4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "pgpu_trace_bvh8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.c_int, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
+    "pgpu_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.c_int, C.POINTER(Hits), C.c_void_p, C.POINTER(Counters), C.c_void_p]),
+    "pgpu_last_kernel_ms": (C.c_float, [C.c_void_p]),
+    "pgpu_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgpu_set_stats": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgpu_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "pgpu_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C pandora_amd` (no fallback exists)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def ptr(a) -> int:
+    """Address of a numpy array or torch tensor (host or device)."""
+    if a is None:
+        return 0
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return int(a.data_ptr())
+
+
+class PandoraError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pandora_hip error {code}: {msg}")
+        self.code = code
+
+
+def view(addr: int, n: int, dtype) -> np.ndarray:
+    """numpy view (no copy) of n elements at a host address owned by the library."""
+    dt = np.dtype(dtype)
+    if n == 0:
+        return np.empty(0, dt)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dt, count=n)

@@ -1,0 +1,411 @@
+// C-ABI implementation: device context, scene upload, batch tracing. See include/pandora_hip.h.
+#include "context.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace pandora_hip;
+
+namespace {
+
+int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                       \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess)                                    \
+            return fail((ctx), PGPU_ERR_HIP, #call, e_);         \
+    } while (0)
+
+template <typename T>
+int uploadArray(pgpu_ctx* c, const T* host, size_t n, T** dev)
+{
+    *dev = nullptr;
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    c->owned.push_back(p);
+    if (n)
+        HIP_TRY(c, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T*>(p);
+    return PGPU_OK;
+}
+
+int ensure(pgpu_ctx* c, DeviceBuffer& b, size_t bytes)
+{
+    if (b.bytes >= bytes)
+        return PGPU_OK;
+    if (b.ptr)
+        HIP_TRY(c, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    HIP_TRY(c, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return PGPU_OK;
+}
+
+int syncBvhTable(pgpu_ctx* c)
+{
+    if (!c->bvhTableDirty)
+        return PGPU_OK;
+    if (c->bvhTableCap < c->bvhs.size()) {
+        if (c->bvhTable)
+            HIP_TRY(c, hipFree(c->bvhTable));
+        c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
+    }
+    HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
+    c->bvhTableDirty = false;
+    return PGPU_OK;
+}
+
+// Longest chain of nested inner nodes; also validates every handle. Returns -1 on a malformed tree.
+int bvh8Depth(const unsigned char* nodes, size_t nNodes, size_t nIdx, uint32_t root)
+{
+    struct E {
+        uint32_t h;
+        int d;
+    };
+    std::vector<E> todo { { root, 0 } };
+    int deepest = 0;
+    size_t visited = 0;
+    while (!todo.empty()) {
+        const E e = todo.back();
+        todo.pop_back();
+        const uint32_t flags = e.h >> 29, index = e.h & 0x1FFFFFFFu;
+        if (flags == 2u) {
+            if (index >= nNodes || ++visited > nNodes)
+                return -1;
+            deepest = std::max(deepest, e.d + 1);
+            const uint32_t* kids = reinterpret_cast<const uint32_t*>(nodes + size_t(index) * 256 + 192);
+            for (int i = 0; i < 8; ++i)
+                if (kids[i] != 0u)
+                    todo.push_back({ kids[i], e.d + 1 });
+        } else if (flags & 4u) {
+            if (size_t(index) + ((flags & 3u) + 1u) > nIdx)
+                return -1;
+        } else {
+            return -1; // reserved flag patterns 001 / 011 (000 = empty is skipped above)
+        }
+    }
+    return deepest;
+}
+
+struct RayPtrs {
+    const float* p[8];
+};
+
+} // namespace
+
+extern "C" {
+
+const char* pgpu_version(void) { return "pandora_hip 0.1 (gfx950)"; }
+
+int pgpu_init(int device_id, pgpu_ctx** out)
+{
+    if (!out)
+        return PGPU_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return PGPU_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count)
+        return PGPU_ERR_INVALID;
+    pgpu_ctx* c = new (std::nothrow) pgpu_ctx();
+    if (!c)
+        return PGPU_ERR_INVALID;
+    c->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess)
+        e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&c->cursor), 256);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&c->statsDev), 64);
+    if (e == hipSuccess)
+        e = hipMemset(c->statsDev, 0, 64);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess)
+        e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        delete c;
+        return PGPU_ERR_HIP;
+    }
+    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return PGPU_OK;
+}
+
+void pgpu_shutdown(pgpu_ctx* c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->owned)
+        (void)hipFree(p);
+    if (c->bvhTable)
+        (void)hipFree(c->bvhTable);
+    if (c->cursor)
+        (void)hipFree(c->cursor);
+    if (c->statsDev)
+        (void)hipFree(c->statsDev);
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work })
+        if (b->ptr)
+            (void)hipFree(b->ptr);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* pgpu_last_error(const pgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+float pgpu_last_kernel_ms(const pgpu_ctx* c) { return c ? c->lastKernelMs : 0.0f; }
+
+int pgpu_set_stats(pgpu_ctx* c, int enabled)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    c->stats = enabled != 0;
+    return PGPU_OK;
+}
+
+int pgpu_set_tuning(pgpu_ctx* c, int blocks_per_cu, int chunk)
+{
+    if (!c || blocks_per_cu < 1 || blocks_per_cu > 8 || chunk < 8 || chunk > 65536)
+        return PGPU_ERR_INVALID;
+    c->blocksPerCU = blocks_per_cu;
+    c->chunk = uint32_t(chunk);
+    return PGPU_OK;
+}
+
+int pgpu_get_counters(pgpu_ctx* c, pgpu_counters* out)
+{
+    if (!c || !out)
+        return PGPU_ERR_INVALID;
+    *out = c->counters;
+    return PGPU_OK;
+}
+
+int pgpu_upload_mesh(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    uint32_t* mesh_id)
+{
+    if (!c || !positions || !indices || !mesh_id || n_vertices == 0 || n_triangles == 0)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_mesh: null or empty argument");
+    for (size_t i = 0; i < 3 * n_triangles; ++i)
+        if (indices[i] >= n_vertices)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_mesh: vertex index out of range");
+    HostMesh m;
+    m.pos.assign(positions, positions + 3 * n_vertices);
+    m.idx.assign(indices, indices + 3 * n_triangles);
+    c->meshes.push_back(std::move(m));
+    *mesh_id = uint32_t(c->meshes.size() - 1);
+    return PGPU_OK;
+}
+
+int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id)
+{
+    if (!c || !leaf_indices || !objs || !bvh_id || n_indices == 0 || n_objs == 0 || (n_nodes && !nodes256))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: null or empty argument");
+    if (n_nodes >= (1u << 29) || n_indices >= (1u << 29))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: more than 2^29 nodes or leaf indices");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int depth = bvh8Depth(static_cast<const unsigned char*>(nodes256), n_nodes, n_indices, root_handle);
+    if (depth < 0)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: malformed tree (handle out of range or cycle)");
+    if (7 * depth + 8 > 96) // the 96-entry traversal stack of wive_bvh8_impl.h:74-75
+        return fail(c, PGPU_ERR_DEPTH, "pgpu_upload_bvh8: more than 12 nested inner nodes");
+    // gather every leaf slot's triangle once (see Bvh8Dev in kernels.h)
+    std::vector<float> tris(n_indices * 12, 0.0f);
+    for (size_t s = 0; s < n_indices; ++s) {
+        const uint32_t obj = leaf_indices[s];
+        if (obj >= n_objs)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: leaf index beyond the leaf-object table");
+        const pgpu_leafobj lo = objs[obj];
+        if (lo.mesh >= c->meshes.size())
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: unknown mesh id");
+        const HostMesh& m = c->meshes[lo.mesh];
+        if (size_t(lo.prim) * 3 + 2 >= m.idx.size())
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: primitive id out of range");
+        float* t = &tris[s * 12];
+        for (int k = 0; k < 3; ++k) {
+            const float* p = &m.pos[size_t(m.idx[size_t(lo.prim) * 3 + size_t(k)]) * 3];
+            t[4 * k + 0] = p[0];
+            t[4 * k + 1] = p[1];
+            t[4 * k + 2] = p[2];
+        }
+        std::memcpy(&t[3], &obj, 4);
+    }
+    Bvh8Dev d {};
+    unsigned char* devNodes = nullptr;
+    float* devTris = nullptr;
+    int rc = uploadArray(c, static_cast<const unsigned char*>(nodes256), n_nodes * 256, &devNodes);
+    if (rc != PGPU_OK)
+        return rc;
+    rc = uploadArray(c, tris.data(), tris.size(), &devTris);
+    if (rc != PGPU_OK)
+        return rc;
+    d.nodes = devNodes;
+    d.tris = reinterpret_cast<const unsigned char*>(devTris);
+    d.root = root_handle;
+    d.n_nodes = uint32_t(n_nodes);
+    d.n_slots = uint32_t(n_indices);
+    d.depth = uint32_t(depth);
+    c->bvhs.push_back(d);
+    c->bvhTableDirty = true;
+    *bvh_id = uint32_t(c->bvhs.size() - 1);
+    return PGPU_OK;
+}
+
+int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
+    const pgpu_hits* hits, uint32_t* any_hit, void* stream_)
+{
+    if (!c || !rays)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: null argument");
+    if (bvh_id >= c->bvhs.size())
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_bvh8: unknown bvh id");
+    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: kind must be PGPU_CLOSEST or PGPU_ANY");
+    if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: unknown triangle test");
+    if (kind == PGPU_CLOSEST && (!hits || !hits->t || !hits->obj || !hits->leaf || !hits->u || !hits->v))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: closest-hit needs t, obj, leaf, u, v arrays");
+    if (kind == PGPU_ANY && !any_hit)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: any-hit needs the any_hit array");
+    if (n > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: batch too large");
+    const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, rays->tfar };
+    for (const float* p : rp)
+        if (!p && n)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: null ray array");
+    if (n == 0)
+        return PGPU_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = syncBvhTable(c);
+    if (rc != PGPU_OK)
+        return rc;
+    hipStream_t stream = (mem == PGPU_MEM_DEVICE && stream_) ? static_cast<hipStream_t>(stream_) : c->stream;
+
+    Bvh8TraceArgs a {};
+    float* hostOut[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    if (mem == PGPU_MEM_HOST) {
+        rc = ensure(c, c->stageRays, n * 8 * sizeof(float));
+        if (rc != PGPU_OK)
+            return rc;
+        rc = ensure(c, c->stageHits, n * 6 * sizeof(float));
+        if (rc != PGPU_OK)
+            return rc;
+        float* dr = static_cast<float*>(c->stageRays.ptr);
+        for (int i = 0; i < 8; ++i)
+            HIP_TRY(c, hipMemcpyAsync(dr + size_t(i) * n, rp[i], n * sizeof(float), hipMemcpyHostToDevice, stream));
+        for (int i = 0; i < 8; ++i)
+            rp[i] = dr + size_t(i) * n;
+        float* dh = static_cast<float*>(c->stageHits.ptr);
+        for (int i = 0; i < 5; ++i)
+            hostOut[i] = dh + size_t(i) * n;
+        a.t_out = hostOut[0];
+        a.obj_out = reinterpret_cast<uint32_t*>(hostOut[1]);
+        a.leaf_out = reinterpret_cast<uint32_t*>(hostOut[2]);
+        a.u_out = hostOut[3];
+        a.v_out = hostOut[4];
+        a.any_out = reinterpret_cast<uint32_t*>(dh + size_t(5) * n);
+    } else if (mem == PGPU_MEM_DEVICE) {
+        if (kind == PGPU_CLOSEST) {
+            a.t_out = hits->t;
+            a.obj_out = hits->obj;
+            a.leaf_out = hits->leaf;
+            a.u_out = hits->u;
+            a.v_out = hits->v;
+        }
+        a.any_out = any_hit;
+    } else {
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: mem must be PGPU_MEM_HOST or PGPU_MEM_DEVICE");
+    }
+    a.bvhs = c->bvhTable;
+    a.work_ray = nullptr;
+    a.work_bvh = nullptr;
+    a.fixed_bvh = bvh_id;
+    a.n_work = uint32_t(n);
+    a.ox = rp[0];
+    a.oy = rp[1];
+    a.oz = rp[2];
+    a.dx = rp[3];
+    a.dy = rp[4];
+    a.dz = rp[5];
+    a.tnear = rp[6];
+    a.tfar_in = rp[7];
+    a.cursor = c->cursor;
+    a.chunk = c->chunk;
+    a.init_miss = 1;
+    a.stats = c->stats ? c->statsDev : nullptr;
+
+    HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+    if (c->stats)
+        HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
+    const uint32_t maxBlocks = uint32_t(c->numCUs * c->blocksPerCU);
+    const uint32_t wantBlocks = uint32_t((n + 31) / 32); // 32 rays in flight per 256-thread block
+    const uint32_t blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    HIP_TRY(c, launchBvh8Trace(a, kind, tri_mode, c->stats, blocks, stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+
+    if (mem == PGPU_MEM_HOST) {
+        if (kind == PGPU_CLOSEST) {
+            void* dst[5] = { hits->t, hits->obj, hits->leaf, hits->u, hits->v };
+            for (int i = 0; i < 5; ++i)
+                HIP_TRY(c, hipMemcpyAsync(dst[i], hostOut[i], n * 4, hipMemcpyDeviceToHost, stream));
+            if (hits->visits)
+                std::memset(hits->visits, 0, n * 4);
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(any_hit, a.any_out, n * 4, hipMemcpyDeviceToHost, stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
+        if (c->stats) {
+            unsigned long long s[3];
+            HIP_TRY(c, hipMemcpy(s, c->statsDev, sizeof(s), hipMemcpyDeviceToHost));
+            c->counters = pgpu_counters {};
+            c->counters.inner_visits = s[0];
+            c->counters.leaf_pops = s[1];
+            c->counters.tri_tests = s[2];
+        }
+    }
+    return PGPU_OK;
+}
+
+// Blocks until the context's last device-memory trace has finished and refreshes the timing / counters.
+int pgpu_sync(pgpu_ctx* c, void* stream_)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    if (hipEventQuery(c->ev1) == hipSuccess)
+        (void)hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1);
+    if (c->stats) {
+        unsigned long long s[3];
+        HIP_TRY(c, hipMemcpy(s, c->statsDev, sizeof(s), hipMemcpyDeviceToHost));
+        c->counters.inner_visits = s[0];
+        c->counters.leaf_pops = s[1];
+        c->counters.tri_tests = s[2];
+    }
+    return PGPU_OK;
+}
+}

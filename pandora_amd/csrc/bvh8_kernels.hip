@@ -1,0 +1,423 @@
+// Bottom-level WiVe BVH8 traversal for MI355X (gfx950, wave64).
+//
+// Reference semantics: WiVeBVH8::intersect / intersectAny / intersectInnerNode / intersectLeaf
+//   projects/pandora/include/pandora/traversal/bvh/wive_bvh8_impl.h:57-140, :142-201, :209-238, :272-290
+// and the leaf test TriangleShape::intersectPrimitive
+//   projects/pandora/src/shapes/triangle_intersect.cpp:425-462 (Moller-Trumbore, the compiled branch)
+//   and :340-423 (watertight variant, selectable).
+//
+// Mapping. The reference runs one ray at a time with the 8 children of a node in the 8 lanes of a
+// ymm register. Here a wave64 carries 8 rays; the 8 lanes of a "ray group" play the role of the 8
+// AVX2 lanes. Per step every group pops one stack entry and the wave issues two LDS-DMA loads
+// (global_load_lds_dwordx4) that bring the 8 x 256-byte nodes -- or the <=4 x 48-byte leaf triangles
+// -- of its 8 rays into LDS, 16 cache lines per wave step instead of 64 for per-lane gathers.
+// Child ordering is the node's precomputed octant permutation applied with ds_bpermute, hits are
+// compacted with a wave ballot + popcount prefix and pushed to a per-ray 96-entry stack in LDS.
+// Waves are persistent: they draw chunks of rays from a global cursor until it runs out.
+//
+// The reference compacts its whole stack after every leaf hit (dist < tfar). Order is preserved by
+// that compaction, so culling lazily at pop time is equivalent: entries pushed before the last hit
+// (index < hitMark) must satisfy dist < tfar, entries pushed after it are kept unconditionally.
+//
+// Float semantics: contraction off; min/max written as compare+select so that NaN behaves like
+// x86 minps/maxps (second operand wins), see SURVEY.md F10.
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+
+#pragma clang fp contract(off)
+
+namespace pandora_hip {
+
+namespace {
+
+constexpr uint32_t kWavesPerBlock = 4;
+constexpr uint32_t kStageBytesPerWave = 2048;          // 8 rays x 256 B
+constexpr uint32_t kStackEntries = 96;                 // wive_bvh8_impl.h:74-75
+constexpr uint32_t kStackStride = kStackEntries * 8 + 64; // +64 B: odd groups start 16 banks later
+constexpr uint32_t kLdsBytes = kWavesPerBlock * kStageBytesPerWave + kWavesPerBlock * 8 * kStackStride;
+
+__device__ __forceinline__ float min86(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float max86(float a, float b) { return a > b ? a : b; }
+
+__device__ __forceinline__ void ldsDma16(const unsigned char* gsrc, unsigned char* ldsWaveBase)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)ldsWaveBase, 16, 0, 0);
+}
+
+__device__ __forceinline__ float ldsF(const unsigned char* p) { return *reinterpret_cast<const float*>(p); }
+__device__ __forceinline__ uint32_t ldsU(const unsigned char* p) { return *reinterpret_cast<const uint32_t*>(p); }
+
+struct TriHit {
+    float t, u, v;
+    bool hit;
+};
+
+// triangle_intersect.cpp:425-462, operation order kept (glm::cross / glm::dot expansion)
+__device__ __forceinline__ TriHit triMT(float ox, float oy, float oz, float dx, float dy, float dz, float tnear, float tfar,
+    float4 a, float4 b, float4 c)
+{
+    TriHit r;
+    r.hit = false;
+    r.t = r.u = r.v = 0.0f;
+    const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+    const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+    const float hx = dy * e2z - e2y * dz;
+    const float hy = dz * e2x - e2z * dx;
+    const float hz = dx * e2y - e2x * dy;
+    const float det = (e1x * hx + e1y * hy) + e1z * hz;
+    if (det > -0.000001f && det < 0.000001f)
+        return r;
+    const float f = 1.0f / det;
+    const float sx = ox - a.x, sy = oy - a.y, sz = oz - a.z;
+    const float u = f * ((sx * hx + sy * hy) + sz * hz);
+    if (u < 0.0f || u > 1.0f)
+        return r;
+    const float qx = sy * e1z - e1y * sz;
+    const float qy = sz * e1x - e1z * sx;
+    const float qz = sx * e1y - e1x * sy;
+    const float v = f * ((dx * qx + dy * qy) + dz * qz);
+    if (v < 0.0f || u + v > 1.0f)
+        return r;
+    const float t = f * ((e2x * qx + e2y * qy) + e2z * qz);
+    if (t < tnear || t > tfar)
+        return r;
+    r.hit = true;
+    r.t = t;
+    r.u = u;
+    r.v = v;
+    return r;
+}
+
+// triangle_intersect.cpp:340-423 (PBRT-v3 watertight test with the double-precision edge fallback)
+__device__ __forceinline__ TriHit triWatertight(float ox, float oy, float oz, float dx, float dy, float dz, float tnear, float tfar,
+    float4 a, float4 b, float4 c)
+{
+    TriHit r;
+    r.hit = false;
+    r.t = r.u = r.v = 0.0f;
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    const int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+    float p0[3] = { a.x - ox, a.y - oy, a.z - oz };
+    float p1[3] = { b.x - ox, b.y - oy, b.z - oz };
+    float p2[3] = { c.x - ox, c.y - oy, c.z - oz };
+    float d[3] = { dx, dy, dz };
+    // permute(v, kx, ky, kz) with kx = kz+1, ky = kx+1 (mod 3), written as selects to stay in registers
+    auto sel = [](const float* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : v[2]); };
+    const int kx = kz == 2 ? 0 : kz + 1;
+    const int ky = kx == 2 ? 0 : kx + 1;
+    const float ddx = sel(d, kx), ddy = sel(d, ky), ddz = sel(d, kz);
+    float p0x = sel(p0, kx), p0y = sel(p0, ky), p0z = sel(p0, kz);
+    float p1x = sel(p1, kx), p1y = sel(p1, ky), p1z = sel(p1, kz);
+    float p2x = sel(p2, kx), p2y = sel(p2, ky), p2z = sel(p2, kz);
+    const float Sx = -ddx / ddz, Sy = -ddy / ddz, Sz = 1.0f / ddz;
+    p0x += Sx * p0z;
+    p0y += Sy * p0z;
+    p1x += Sx * p1z;
+    p1y += Sy * p1z;
+    p2x += Sx * p2z;
+    p2y += Sy * p2z;
+    float e0 = p1x * p2y - p1y * p2x;
+    float e1 = p2x * p0y - p2y * p0x;
+    float e2 = p0x * p1y - p0y * p1x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        const double p2txp1ty = (double)p2x * (double)p1y;
+        const double p2typ1tx = (double)p2y * (double)p1x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        const double p0txp2ty = (double)p0x * (double)p2y;
+        const double p0typ2tx = (double)p0y * (double)p2x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        const double p1txp0ty = (double)p1x * (double)p0y;
+        const double p1typ0tx = (double)p1y * (double)p0x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f))
+        return r;
+    const float det = e0 + e1 + e2;
+    if (det == 0.0f)
+        return r;
+    p0z *= Sz;
+    p1z *= Sz;
+    p2z *= Sz;
+    const float tScaled = e0 * p0z + e1 * p1z + e2 * p2z;
+    if (det < 0.0f && (tScaled >= tnear * det || tScaled < tfar * det))
+        return r;
+    else if (det > 0.0f && (tScaled <= tnear * det || tScaled > tfar * det))
+        return r;
+    const float invDet = 1.0f / det;
+    r.hit = true;
+    r.u = e0 * invDet;
+    r.v = e1 * invDet;
+    r.t = tScaled * invDet;
+    return r;
+}
+
+template <bool ANY, int TRI, bool STATS>
+__global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
+{
+    __shared__ __align__(16) unsigned char lds[kLdsBytes];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t g = lane >> 3, k = lane & 7u;
+    const uint32_t s = g & 3u; // piece swizzle: groups of one half-wave read disjoint LDS banks
+    unsigned char* const stage = lds + wave * kStageBytesPerWave;
+    uint2* const stack = reinterpret_cast<uint2*>(lds + kWavesPerBlock * kStageBytesPerWave + (wave * 8u + g) * kStackStride);
+    const uint32_t groupShift = g * 8u;
+    const uint64_t oneBitPerGroup = 0x0101010101010101ull;
+
+    // LDS read addresses of this lane: child k of node array j (minX,maxX,minY,maxY | minZ,maxZ,children,perm)
+    const unsigned char* nodeRd[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j)
+        nodeRd[j] = stage + (j >> 2) * 1024u + g * 128u + (((j & 3u) ^ s) * 32u) + k * 4u;
+    // triangle k of a leaf: 16-byte pieces 3k, 3k+1, 3k+2
+    const unsigned char* triRd[3];
+#pragma unroll
+    for (uint32_t j = 0; j < 3; ++j) {
+        const uint32_t p = 3u * (k & 3u) + j;
+        triRd[j] = stage + (p >> 3) * 1024u + (g * 8u + ((p & 7u) ^ (s << 1))) * 16u;
+    }
+    const uint32_t myPiece = k ^ (s << 1); // which 16-byte piece of each 128-byte half this lane fetches
+
+    // per-ray state, replicated over the 8 lanes of the group
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
+    float hitU = 0, hitV = 0;
+    uint32_t hitObj = PGPU_MISS_ID, shift = 0, rayId = 0, bvhId = 0;
+    const unsigned char* nodes = nullptr;
+    const unsigned char* tris = nullptr;
+    int sp = 0, hitMark = 0;
+    bool active = false;
+    uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
+    bool exhausted = false;
+    uint32_t statInner = 0, statLeaf = 0, statTri = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------ refill idle groups
+        const uint64_t idle = __ballot(!active) & oneBitPerGroup;
+        if (idle != 0 && !exhausted) {
+            if (chunkNext >= chunkEnd) {
+                uint32_t c = 0;
+                if (lane == 0)
+                    c = atomicAdd(a.cursor, a.chunk);
+                c = __builtin_amdgcn_readfirstlane(c);
+                chunkNext = c;
+                chunkEnd = min(c + a.chunk, a.n_work);
+                if (c >= a.n_work) {
+                    exhausted = true;
+                    chunkEnd = chunkNext;
+                }
+            }
+            const uint32_t need = __popcll(idle);
+            const uint32_t rank = __popcll(idle & ((1ull << groupShift) - 1ull));
+            const uint32_t w = chunkNext + rank;
+            const bool take = !active && w < chunkEnd;
+            chunkNext = min(chunkNext + need, chunkEnd);
+            if (take) {
+                rayId = a.work_ray ? a.work_ray[w] : w;
+                bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
+                const Bvh8Dev bd = a.bvhs[bvhId];
+                nodes = bd.nodes;
+                tris = bd.tris;
+                ox = a.ox[rayId];
+                oy = a.oy[rayId];
+                oz = a.oz[rayId];
+                dx = a.dx[rayId];
+                dy = a.dy[rayId];
+                dz = a.dz[rayId];
+                tnear = a.tnear[rayId];
+                tfar = a.tfar_in[rayId];
+                ix = 1.0f / dx; // wive_bvh8_impl.h:66-68: no zero guard
+                iy = 1.0f / dy;
+                iz = 1.0f / dz;
+                shift = ((dx > 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dz > 0 ? 4u : 0u)) * 3u; // :384-388
+                hitObj = PGPU_MISS_ID;
+                hitU = hitV = 0.0f;
+                if (k == 0)
+                    stack[0] = make_uint2(bd.root, __float_as_uint(0.0f)); // :80-82
+                sp = 1;
+                hitMark = 0;
+                active = true;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (__ballot(active) == 0) {
+            if (exhausted)
+                break;
+            continue;
+        }
+
+        // ------------------------------------------------------------ pop: 8 top entries at once
+        uint32_t handle = 0;
+        bool have = false;
+        {
+            const int e = sp - 1 - int(k);
+            uint2 ent = make_uint2(0u, 0u);
+            if (active && e >= 0)
+                ent = stack[e];
+            const bool ok = active && e >= 0 && (e >= hitMark || __uint_as_float(ent.y) < tfar);
+            const uint32_t gb = uint32_t(__ballot(ok) >> groupShift) & 0xFFu;
+            const uint32_t first = gb != 0 ? uint32_t(__builtin_ctz(gb)) : 0u;
+            handle = uint32_t(__builtin_amdgcn_ds_bpermute(int((lane - k + first) << 2), int(ent.x)));
+            if (active) {
+                if (gb != 0) {
+                    sp = sp - 1 - int(first);
+                    have = true;
+                } else {
+                    sp = max(sp - 8, 0); // all 8 candidates were culled
+                }
+                hitMark = min(hitMark, sp);
+            }
+        }
+
+        const bool isInner = have && (handle >> 29) == 2u;
+        const bool isLeaf = have && !isInner;
+        const uint32_t index = handle & 0x1FFFFFFFu;
+        const uint32_t count = ((handle >> 29) & 3u) + 1u; // :378-382
+
+        // ------------------------------------------------------------ fetch node / leaf triangles into LDS
+        {
+            const unsigned char* base = isInner ? nodes + size_t(index) * 256u : tris + size_t(index) * 48u;
+            const uint32_t pieces = isInner ? 16u : 3u * count;
+            if (have && myPiece < pieces)
+                ldsDma16(base + myPiece * 16u, stage);
+            if (have && myPiece + 8u < pieces)
+                ldsDma16(base + 128u + myPiece * 16u, stage + 1024u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+
+        // ------------------------------------------------------------ inner node: slab test of child k
+        if (isInner) {
+            const float lox = ldsF(nodeRd[0]), hix = ldsF(nodeRd[1]);
+            const float loy = ldsF(nodeRd[2]), hiy = ldsF(nodeRd[3]);
+            const float loz = ldsF(nodeRd[4]), hiz = ldsF(nodeRd[5]);
+            const uint32_t child = ldsU(nodeRd[6]);
+            const uint32_t perm = ldsU(nodeRd[7]);
+            const float tx1 = (lox - ox) * ix, tx2 = (hix - ox) * ix; // :212-217
+            const float ty1 = (loy - oy) * iy, ty2 = (hiy - oy) * iy;
+            const float tz1 = (loz - oz) * iz, tz2 = (hiz - oz) * iz;
+            const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
+            const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
+            const float tmin = max86(tnear, max86(txMin, max86(tyMin, tzMin))); // :224
+            const float tmax = min86(tfar, min86(txMax, min86(tyMax, tzMax)));  // :225
+            const bool overlap = tmin <= tmax;                                   // :233
+            // slot k takes the child named by the octant permutation (:229-232,235)
+            const uint32_t src = (lane - k) + ((perm >> shift) & 7u);
+            const uint32_t pChild = uint32_t(__builtin_amdgcn_ds_bpermute(int(src << 2), int(overlap ? child : 0xFFFFFFFFu)));
+            const float pTmin = __int_as_float(__builtin_amdgcn_ds_bpermute(int(src << 2), __float_as_int(tmin)));
+            const bool keep = pChild != 0xFFFFFFFFu;
+            // compress (:234-237): rank among the kept slots of this group
+            const uint32_t gb = uint32_t(__ballot(keep) >> groupShift) & 0xFFu;
+            const uint32_t rank = __popc(gb & ((1u << k) - 1u));
+            if (keep)
+                stack[sp + int(rank)] = make_uint2(pChild, __float_as_uint(pTmin));
+            sp += int(__popc(gb));
+            if (STATS)
+                statInner += (k == 0);
+        }
+
+        // ------------------------------------------------------------ leaf: <= 4 triangles, one per lane
+        if (isLeaf) {
+            TriHit th;
+            th.hit = false;
+            th.t = th.u = th.v = 0.0f;
+            uint32_t obj = 0;
+            if (k < count) {
+                const float4 p0 = *reinterpret_cast<const float4*>(triRd[0]);
+                const float4 p1 = *reinterpret_cast<const float4*>(triRd[1]);
+                const float4 p2 = *reinterpret_cast<const float4*>(triRd[2]);
+                obj = __float_as_uint(p0.w);
+                th = TRI == PGPU_TRI_WATERTIGHT_ID ? triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2)
+                                                   : triMT(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2);
+                if (STATS)
+                    statTri += 1;
+            }
+            if (STATS)
+                statLeaf += (k == 0);
+            // The reference tests the leaf's objects in order, each seeing the tfar left by the previous
+            // one and accepting t <= tfar (:272-280). The survivor of that sequence is the LAST object
+            // whose t equals the minimum of the valid t's.
+            float best = th.hit ? th.t : __builtin_inff();
+            best = fminf(best, __shfl_xor(best, 1));
+            best = fminf(best, __shfl_xor(best, 2));
+            const bool winner = th.hit && th.t == best;
+            const uint32_t gb = uint32_t(__ballot(winner) >> groupShift) & 0xFu;
+            if (gb != 0) {
+                const uint32_t w = 31u - __builtin_clz(gb);
+                const int srcAddr = int((lane - k + w) << 2);
+                if (ANY) {
+                    // :193-196: first hit ends the ray
+                    if (k == 0)
+                        a.any_out[rayId] = 1u;
+                    active = false;
+                    sp = 0;
+                } else {
+                    tfar = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.t)));
+                    hitU = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.u)));
+                    hitV = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.v)));
+                    hitObj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, int(obj)));
+                    hitMark = sp; // everything still on the stack predates this hit
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ retire rays whose stack ran dry
+        if (active && sp == 0) {
+            if (k == 0) {
+                if (ANY) {
+                    if (a.init_miss)
+                        a.any_out[rayId] = 0u;
+                } else {
+                    a.t_out[rayId] = tfar;
+                    if (hitObj != PGPU_MISS_ID) {
+                        a.obj_out[rayId] = hitObj;
+                        a.leaf_out[rayId] = bvhId;
+                        a.u_out[rayId] = hitU;
+                        a.v_out[rayId] = hitV;
+                    } else if (a.init_miss) {
+                        a.obj_out[rayId] = PGPU_MISS_ID;
+                        a.leaf_out[rayId] = 0u;
+                        a.u_out[rayId] = 0.0f;
+                        a.v_out[rayId] = 0.0f;
+                    }
+                }
+            }
+            active = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (STATS && a.stats) {
+        atomicAdd(&a.stats[0], (unsigned long long)statInner);
+        atomicAdd(&a.stats[1], (unsigned long long)statLeaf);
+        atomicAdd(&a.stats[2], (unsigned long long)statTri);
+    }
+}
+
+} // namespace
+
+size_t bvh8TraceLdsBytes() { return kLdsBytes; }
+
+hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
+{
+    const dim3 grid(blocks), block(256);
+#define PANDORA_LAUNCH(ANYV, TRIV, STATV) \
+    hipLaunchKernelGGL((bvh8TraceKernel<ANYV, TRIV, STATV>), grid, block, 0, stream, args)
+    if (kind == PGPU_ANY_ID) {
+        if (triMode == PGPU_TRI_WATERTIGHT_ID) {
+            if (stats) PANDORA_LAUNCH(true, 1, true); else PANDORA_LAUNCH(true, 1, false);
+        } else {
+            if (stats) PANDORA_LAUNCH(true, 0, true); else PANDORA_LAUNCH(true, 0, false);
+        }
+    } else {
+        if (triMode == PGPU_TRI_WATERTIGHT_ID) {
+            if (stats) PANDORA_LAUNCH(false, 1, true); else PANDORA_LAUNCH(false, 1, false);
+        } else {
+            if (stats) PANDORA_LAUNCH(false, 0, true); else PANDORA_LAUNCH(false, 0, false);
+        }
+    }
+#undef PANDORA_LAUNCH
+    return hipGetLastError();
+}
+
+} // namespace pandora_hip

@@ -1,0 +1,47 @@
+// Device context behind the opaque pgpu_ctx of include/pandora_hip.h.
+#pragma once
+#include "kernels.h"
+#include "pandora_hip.h"
+#include <string>
+#include <vector>
+
+struct HostMesh {
+    std::vector<float> pos;
+    std::vector<uint32_t> idx;
+};
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct pgpu_ctx {
+    int device = 0;
+    int numCUs = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    float lastKernelMs = 0.0f;
+    bool stats = false;
+    int blocksPerCU = 4;
+    uint32_t chunk = 64;
+
+    std::vector<HostMesh> meshes;
+    std::vector<pandora_hip::Bvh8Dev> bvhs; // host mirror of the device table
+    std::vector<void*> owned;               // every hipMalloc'd scene buffer
+    pandora_hip::Bvh8Dev* bvhTable = nullptr;
+    size_t bvhTableCap = 0;
+    bool bvhTableDirty = true;
+
+    uint32_t* cursor = nullptr;          // work cursors (one u32 per launch slot)
+    unsigned long long* statsDev = nullptr; // inner visits, leaf pops, tri tests
+    pgpu_counters counters {};
+
+    // staging for host-resident ray batches: 8 ray arrays + 5 hit arrays + any/visits
+    DeviceBuffer stageRays, stageHits;
+
+    // two-level state (top_kernels.hip)
+    pandora_hip::TopDev top {};
+    bool haveTop = false;
+    DeviceBuffer work; // per-ray traversal state + queues, grown on demand
+};

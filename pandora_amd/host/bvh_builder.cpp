@@ -1,0 +1,507 @@
+// Host-side acceleration-structure construction for the MI355X traversal path.
+//
+// The reference delegates every BVH build to Embree 3's rtcBuildBVH (bottom level:
+// wive_bvh8_build8_impl.h:87-104, branching 8, leaves 1..4; top level: pauseable_bvh4.h:160-176,
+// branching 4, one batching point per leaf; scene cut: batching.cpp:106-159). Embree is not part of
+// this system, so this file is an own top-down binned-SAH wide builder that emits the reference's
+// node layouts bit for bit (256-byte BVH8 node with the 24-bit octant permutation words of
+// wive_bvh8_build8_impl.h:172-203; 112-byte BVH4 node in the DFS order of pauseable_bvh4.h:398-483).
+// Tree topology therefore differs from an Embree-built tree; hit parity is defined per tree.
+//
+// Depth is bounded by construction: the bottom level never nests more than kMaxInnerDepth8 inner
+// nodes so that the traversal stack (7 * depth + 8 entries, wive_bvh8_impl.h:74,97-102) fits the
+// reference's 96 entries, and the top level stays within 16 levels (4 stack bits per level in a
+// 64-bit word, pauseable_bvh4.h:262-263).
+#include "pandora_hip.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+constexpr int kBins = 16;
+constexpr int kMaxInnerDepth8 = 12; // 7*12 + 8 <= 96
+constexpr int kMaxDepth4 = 15;      // depth field 0..15
+
+struct Box {
+    float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX };
+    float hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    void grow(const float* p)
+    {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void grow(const Box& b)
+    {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], b.lo[a]);
+            hi[a] = std::max(hi[a], b.hi[a]);
+        }
+    }
+    float halfArea() const
+    {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Item {
+    Box box;
+    float c[3];
+    uint32_t id;
+};
+
+struct Part {
+    size_t begin, end;
+    Box box;
+    size_t count() const { return end - begin; }
+};
+
+Box boundsOf(const std::vector<Item>& items, size_t b, size_t e)
+{
+    Box r;
+    for (size_t i = b; i < e; ++i)
+        r.grow(items[i].box);
+    return r;
+}
+
+// Binned SAH split of items[begin,end); falls back to an index median when every centroid coincides.
+// forceMedian gives the balanced split used when a subtree would otherwise exceed the depth budget.
+size_t splitPart(std::vector<Item>& items, size_t begin, size_t end, bool forceMedian)
+{
+    const size_t n = end - begin;
+    Box cb;
+    for (size_t i = begin; i < end; ++i)
+        cb.grow(items[i].c);
+    int bestAxis = -1, bestBin = -1;
+    float bestCost = FLT_MAX;
+    if (!forceMedian) {
+        for (int a = 0; a < 3; ++a) {
+            const float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.0f))
+                continue;
+            const float scale = float(kBins) / ext;
+            Box bb[kBins];
+            size_t bc[kBins] = {};
+            for (size_t i = begin; i < end; ++i) {
+                int b = std::min(kBins - 1, std::max(0, int((items[i].c[a] - cb.lo[a]) * scale)));
+                bb[b].grow(items[i].box);
+                bc[b]++;
+            }
+            float rightArea[kBins];
+            size_t rightCount[kBins];
+            Box acc;
+            size_t cnt = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                acc.grow(bb[b]);
+                cnt += bc[b];
+                rightArea[b] = cnt ? acc.halfArea() : 0.0f;
+                rightCount[b] = cnt;
+            }
+            acc = Box();
+            cnt = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                acc.grow(bb[b]);
+                cnt += bc[b];
+                if (cnt == 0 || rightCount[b + 1] == 0)
+                    continue;
+                const float cost = acc.halfArea() * float(cnt) + rightArea[b + 1] * float(rightCount[b + 1]);
+                if (cost < bestCost) {
+                    bestCost = cost;
+                    bestAxis = a;
+                    bestBin = b;
+                }
+            }
+        }
+    }
+    if (bestAxis >= 0) {
+        const float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+        const float scale = float(kBins) / ext;
+        const float lo = cb.lo[bestAxis];
+        auto mid = std::partition(items.begin() + begin, items.begin() + end, [&](const Item& it) {
+            int b = std::min(kBins - 1, std::max(0, int((it.c[bestAxis] - lo) * scale)));
+            return b <= bestBin;
+        });
+        size_t m = size_t(mid - items.begin());
+        if (m > begin && m < end)
+            return m;
+    }
+    // median along the widest centroid axis (or plain index median for identical centroids)
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis])
+            axis = a;
+    const size_t m = begin + n / 2;
+    std::nth_element(items.begin() + begin, items.begin() + m, items.begin() + end,
+        [axis](const Item& x, const Item& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.id < y.id); });
+    return m;
+}
+
+// Splits [begin,end) into at most `width` parts, largest surface first; parts of <= maxLeaf items stay whole.
+// capacity = the most items a child subtree may hold given the remaining depth budget.
+std::vector<Part> makeParts(std::vector<Item>& items, size_t begin, size_t end, int width, size_t maxLeaf, double capacity)
+{
+    std::vector<Part> parts;
+    parts.push_back({ begin, end, boundsOf(items, begin, end) });
+    bool balanced = double(end - begin) > capacity * width * 0.5; // close to the budget: go balanced straight away
+    for (;;) {
+        // every part above capacity must be split, whatever its area
+        int pick = -1;
+        float bestArea = -1.0f;
+        bool over = false;
+        for (size_t i = 0; i < parts.size(); ++i) {
+            if (parts[i].count() <= maxLeaf)
+                continue;
+            const bool isOver = double(parts[i].count()) > capacity;
+            const float a = parts[i].box.halfArea();
+            if ((isOver && !over) || (isOver == over && a > bestArea)) {
+                pick = int(i);
+                bestArea = a;
+                over = isOver;
+            }
+        }
+        if (pick < 0 || int(parts.size()) >= width)
+            break;
+        Part p = parts[size_t(pick)];
+        const size_t m = splitPart(items, p.begin, p.end, balanced);
+        parts[size_t(pick)] = { p.begin, m, boundsOf(items, p.begin, m) };
+        parts.insert(parts.begin() + pick + 1, { m, p.end, boundsOf(items, m, p.end) });
+    }
+    bool ok = true;
+    for (const Part& p : parts)
+        if (double(p.count()) > capacity)
+            ok = false;
+    if (!ok && !balanced) {
+        // SAH produced a lopsided cut that the depth budget cannot absorb: redo with median cuts
+        parts.clear();
+        parts.push_back({ begin, end, boundsOf(items, begin, end) });
+        for (;;) {
+            int pick = -1;
+            size_t most = maxLeaf;
+            for (size_t i = 0; i < parts.size(); ++i)
+                if (parts[i].count() > most) {
+                    most = parts[i].count();
+                    pick = int(i);
+                }
+            if (pick < 0 || int(parts.size()) >= width)
+                break;
+            Part p = parts[size_t(pick)];
+            const size_t m = splitPart(items, p.begin, p.end, true);
+            parts[size_t(pick)] = { p.begin, m, boundsOf(items, p.begin, m) };
+            parts.insert(parts.begin() + pick + 1, { m, p.end, boundsOf(items, m, p.end) });
+        }
+    }
+    return parts;
+}
+
+// ---------------------------------------------------------------------------------------------- BVH8
+
+struct Node8 { // wive_bvh8.h:76-86
+    float minX[8], maxX[8], minY[8], maxY[8], minZ[8], maxZ[8];
+    uint32_t children[8];
+    uint32_t perm[8];
+};
+static_assert(sizeof(Node8) == 256, "BVH8 node must be 256 bytes");
+
+inline uint32_t handleInner(uint32_t i) { return (i & 0x1FFFFFFFu) | (2u << 29); }                   // wive_bvh8_impl.h:333-338
+inline uint32_t handleLeaf(uint32_t i, uint32_t n) { return (i & 0x1FFFFFFFu) | ((4u | (n - 1u)) << 29); } // :340-346
+
+// wive_bvh8_build8_impl.h:172-203: for each of the 8 ray-direction octants, child indices ordered
+// back to front; slot i of the word holds the i-th child of that order in bits [shift, shift+3).
+void octantPermutation(const Box* kids, unsigned n, uint32_t perm[8])
+{
+    std::fill(perm, perm + 8, 0u);
+    for (int x = -1; x <= 1; x += 2)
+        for (int y = -1; y <= 1; y += 2)
+            for (int z = -1; z <= 1; z += 2) {
+                float dist[8];
+                uint32_t order[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+                for (unsigned i = 0; i < 8; ++i) {
+                    if (i >= n) {
+                        dist[i] = FLT_MAX;
+                        continue;
+                    }
+                    const float ex = x < 0 ? kids[i].lo[0] : kids[i].hi[0];
+                    const float ey = y < 0 ? kids[i].lo[1] : kids[i].hi[1];
+                    const float ez = z < 0 ? kids[i].lo[2] : kids[i].hi[2];
+                    dist[i] = (ex * float(x) + ey * float(y)) + ez * float(z);
+                }
+                std::stable_sort(order, order + 8, [&](uint32_t a, uint32_t b) { return dist[a] > dist[b]; });
+                const uint32_t shift = ((x > 0 ? 1u : 0u) | (y > 0 ? 2u : 0u) | (z > 0 ? 4u : 0u)) * 3u;
+                for (int i = 0; i < 8; ++i)
+                    perm[i] |= order[i] << shift;
+            }
+}
+
+struct Bvh8Builder {
+    std::vector<Item> items;
+    std::vector<Node8> nodes;
+    std::vector<uint32_t> leafIdx;
+    uint32_t maxLeaf = 4;
+    int maxDepthSeen = 0;
+
+    uint32_t emitLeaf(const Part& p)
+    {
+        const uint32_t at = uint32_t(leafIdx.size());
+        for (size_t i = p.begin; i < p.end; ++i)
+            leafIdx.push_back(items[i].id);
+        return handleLeaf(at, uint32_t(p.count()));
+    }
+
+    // depth = number of inner nodes above this one
+    uint32_t build(const Part& whole, int depth)
+    {
+        if (whole.count() <= maxLeaf)
+            return emitLeaf(whole);
+        maxDepthSeen = std::max(maxDepthSeen, depth + 1);
+        // a child at inner depth d+1 may hold at most maxLeaf * 8^(kMax - (d+1)) items
+        const double capacity = double(maxLeaf) * std::pow(8.0, double(kMaxInnerDepth8 - (depth + 1)));
+        std::vector<Part> parts = makeParts(items, whole.begin, whole.end, 8, maxLeaf, capacity);
+        const uint32_t self = uint32_t(nodes.size());
+        nodes.emplace_back();
+        Box kids[8];
+        uint32_t handles[8];
+        const unsigned n = unsigned(parts.size());
+        for (unsigned i = 0; i < n; ++i) {
+            kids[i] = parts[i].box;
+            handles[i] = build(parts[i], depth + 1);
+        }
+        Node8& nd = nodes[self];
+        std::memset(&nd, 0, sizeof(nd)); // absent children: zero boxes, handle 0 (wive_bvh8_build8_impl.h:142-144,168-170)
+        for (unsigned i = 0; i < n; ++i) {
+            nd.minX[i] = kids[i].lo[0];
+            nd.maxX[i] = kids[i].hi[0];
+            nd.minY[i] = kids[i].lo[1];
+            nd.maxY[i] = kids[i].hi[1];
+            nd.minZ[i] = kids[i].lo[2];
+            nd.maxZ[i] = kids[i].hi[2];
+            nd.children[i] = handles[i];
+        }
+        octantPermutation(kids, n, nd.perm);
+        return handleInner(self);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- BVH4
+
+struct Node4 { // pauseable_bvh4.h:74-98
+    float minX[4], minY[4], minZ[4], maxX[4], maxY[4], maxZ[4];
+    uint32_t firstChild, firstLeaf, parent, bits;
+};
+static_assert(sizeof(Node4) == 112, "BVH4 node must be 112 bytes");
+
+struct Bvh4Builder {
+    std::vector<Item> items;
+    std::vector<Node4> nodes;
+    std::vector<uint32_t> leafOrder; // final leaf slot -> input leaf id
+    int maxDepthSeen = 0;
+
+    // Fills nodes[self] (already allocated) from items[part); mirrors generateFinalBVHRecurse :411-483:
+    // leaf children are appended to the leaf list in child order, inner children get consecutive
+    // node slots allocated before any of them is filled.
+    void fill(uint32_t self, const Part& whole, uint32_t parent, int depth)
+    {
+        maxDepthSeen = std::max(maxDepthSeen, depth);
+        const double capacity = std::pow(4.0, double(kMaxDepth4 - depth));
+        std::vector<Part> parts = makeParts(items, whole.begin, whole.end, 4, 1, capacity);
+        Node4 nd;
+        std::memset(&nd, 0, sizeof(nd));
+        uint32_t valid = 0, leaf = 0;
+        for (size_t i = 0; i < parts.size(); ++i) {
+            nd.minX[i] = parts[i].box.lo[0];
+            nd.minY[i] = parts[i].box.lo[1];
+            nd.minZ[i] = parts[i].box.lo[2];
+            nd.maxX[i] = parts[i].box.hi[0];
+            nd.maxY[i] = parts[i].box.hi[1];
+            nd.maxZ[i] = parts[i].box.hi[2];
+            valid |= 1u << i;
+            if (parts[i].count() == 1)
+                leaf |= 1u << i;
+        }
+        nd.parent = parent;
+        nd.bits = valid | (leaf << 4) | (uint32_t(depth) << 8);
+        if (leaf) {
+            nd.firstLeaf = uint32_t(leafOrder.size());
+            for (size_t i = 0; i < parts.size(); ++i)
+                if (parts[i].count() == 1)
+                    leafOrder.push_back(items[parts[i].begin].id);
+        }
+        const uint32_t nInner = uint32_t(__builtin_popcount(valid & ~leaf));
+        if (nInner) {
+            nd.firstChild = uint32_t(nodes.size());
+            nodes.resize(nodes.size() + nInner);
+        }
+        nodes[self] = nd;
+        uint32_t next = nd.firstChild;
+        for (size_t i = 0; i < parts.size(); ++i)
+            if (parts[i].count() > 1)
+                fill(next++, parts[i], self, depth + 1);
+    }
+};
+
+struct HostBvh8 {
+    std::vector<Node8> nodes;
+    std::vector<uint32_t> leafIdx;
+    uint32_t root = 0;
+    int depth = 0;
+};
+struct HostBvh4 {
+    std::vector<Node4> nodes;
+    std::vector<uint32_t> leafOrder;
+    uint32_t root = 0;
+    int depth = 0;
+};
+
+Item triangleItem(const float* pos, const uint32_t* idx, uint32_t prim, uint32_t id)
+{
+    Item it;
+    for (int k = 0; k < 3; ++k)
+        it.box.grow(pos + 3u * size_t(idx[3u * size_t(prim) + k]));
+    for (int a = 0; a < 3; ++a)
+        it.c[a] = 0.5f * (it.box.lo[a] + it.box.hi[a]);
+    it.id = id;
+    return it;
+}
+
+} // namespace
+
+extern "C" {
+
+struct pgpu_host_bvh8 {
+    HostBvh8 v;
+};
+struct pgpu_host_bvh4 {
+    HostBvh4 v;
+};
+
+int pgpu_build_bvh8(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* prim_ids, size_t n_prims, uint32_t max_leaf, pgpu_host_bvh8** out)
+{
+    if (!positions || !indices || !out || n_prims == 0 || max_leaf < 1 || max_leaf > 4)
+        return PGPU_ERR_INVALID;
+    if (n_prims >= (1u << 29) - 1u)
+        return PGPU_ERR_INVALID;
+    for (size_t j = 0; j < n_prims; ++j) {
+        const size_t p = prim_ids ? prim_ids[j] : j;
+        if (p >= n_triangles)
+            return PGPU_ERR_INVALID;
+        for (int k = 0; k < 3; ++k)
+            if (indices[3 * p + size_t(k)] >= n_vertices)
+                return PGPU_ERR_INVALID;
+    }
+    Bvh8Builder b;
+    b.maxLeaf = max_leaf;
+    b.items.reserve(n_prims);
+    for (size_t j = 0; j < n_prims; ++j) // leaf object j = triangle prim_ids[j] (offline_bvh_cache.cpp:303-304)
+        b.items.push_back(triangleItem(positions, indices, prim_ids ? prim_ids[j] : uint32_t(j), uint32_t(j)));
+    Part whole { 0, n_prims, boundsOf(b.items, 0, n_prims) };
+    auto* r = new pgpu_host_bvh8();
+    r->v.root = b.build(whole, 0);
+    r->v.nodes = std::move(b.nodes);
+    r->v.leafIdx = std::move(b.leafIdx);
+    r->v.depth = b.maxDepthSeen;
+    *out = r;
+    return PGPU_OK;
+}
+
+const void* pgpu_host_bvh8_nodes(const pgpu_host_bvh8* b, size_t* n_nodes)
+{
+    if (n_nodes)
+        *n_nodes = b->v.nodes.size();
+    return b->v.nodes.data();
+}
+const uint32_t* pgpu_host_bvh8_leaf_indices(const pgpu_host_bvh8* b, size_t* n)
+{
+    if (n)
+        *n = b->v.leafIdx.size();
+    return b->v.leafIdx.data();
+}
+uint32_t pgpu_host_bvh8_root(const pgpu_host_bvh8* b) { return b->v.root; }
+int pgpu_host_bvh8_depth(const pgpu_host_bvh8* b) { return b->v.depth; }
+void pgpu_host_bvh8_free(pgpu_host_bvh8* b) { delete b; }
+
+int pgpu_build_top_bvh4(const float* leaf_bounds, size_t n_leaves, pgpu_host_bvh4** out)
+{
+    if (!leaf_bounds || !out)
+        return PGPU_ERR_INVALID;
+    if (n_leaves < 2) // pauseable_bvh4.h:180: a single batching point is rejected by the reference too
+        return PGPU_ERR_SINGLE_LEAF;
+    Bvh4Builder b;
+    b.items.resize(n_leaves);
+    for (size_t i = 0; i < n_leaves; ++i) {
+        Item& it = b.items[i];
+        for (int a = 0; a < 3; ++a) {
+            it.box.lo[a] = leaf_bounds[6 * i + size_t(a)];
+            it.box.hi[a] = leaf_bounds[6 * i + 3 + size_t(a)];
+            it.c[a] = 0.5f * (it.box.lo[a] + it.box.hi[a]);
+        }
+        it.id = uint32_t(i);
+    }
+    b.nodes.emplace_back();
+    b.fill(0, Part { 0, n_leaves, boundsOf(b.items, 0, n_leaves) }, 0, 0);
+    if (b.maxDepthSeen > kMaxDepth4)
+        return PGPU_ERR_DEPTH;
+    auto* r = new pgpu_host_bvh4();
+    r->v.nodes = std::move(b.nodes);
+    r->v.leafOrder = std::move(b.leafOrder);
+    r->v.root = 0;
+    r->v.depth = b.maxDepthSeen;
+    *out = r;
+    return PGPU_OK;
+}
+const void* pgpu_host_bvh4_nodes(const pgpu_host_bvh4* b, size_t* n_nodes)
+{
+    if (n_nodes)
+        *n_nodes = b->v.nodes.size();
+    return b->v.nodes.data();
+}
+const uint32_t* pgpu_host_bvh4_leaf_order(const pgpu_host_bvh4* b, size_t* n)
+{
+    if (n)
+        *n = b->v.leafOrder.size();
+    return b->v.leafOrder.data();
+}
+uint32_t pgpu_host_bvh4_root(const pgpu_host_bvh4* b) { return b->v.root; }
+int pgpu_host_bvh4_depth(const pgpu_host_bvh4* b) { return b->v.depth; }
+void pgpu_host_bvh4_free(pgpu_host_bvh4* b) { delete b; }
+
+// Spatial grouping of triangles into batching points of at most max_prims primitives. The reference
+// cuts an Embree BVH2 over scene objects where a subtree holds <= primitivesPerBatchingPoint
+// (batching.cpp:38-265); here the same rule is applied to a binned-SAH split over triangles.
+int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    size_t max_prims, uint32_t* group_of_prim, uint32_t* n_groups)
+{
+    if (!positions || !indices || !group_of_prim || !n_groups || max_prims == 0)
+        return PGPU_ERR_INVALID;
+    for (size_t i = 0; i < 3 * n_triangles; ++i)
+        if (indices[i] >= n_vertices)
+            return PGPU_ERR_INVALID;
+    std::vector<Item> items;
+    items.reserve(n_triangles);
+    for (size_t p = 0; p < n_triangles; ++p)
+        items.push_back(triangleItem(positions, indices, uint32_t(p), uint32_t(p)));
+    std::vector<std::pair<size_t, size_t>> todo { { 0, n_triangles } };
+    uint32_t g = 0;
+    while (!todo.empty()) {
+        auto [b, e] = todo.back();
+        todo.pop_back();
+        if (e - b <= max_prims) {
+            for (size_t i = b; i < e; ++i)
+                group_of_prim[items[i].id] = g;
+            if (e > b)
+                ++g;
+            continue;
+        }
+        const size_t m = splitPart(items, b, e, false);
+        todo.push_back({ m, e });
+        todo.push_back({ b, m });
+    }
+    *n_groups = g;
+    return PGPU_OK;
+}
+}

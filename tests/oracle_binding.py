@@ -1,0 +1,188 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libpandora_oracle.so) and, when present, of the
+restatement that runs on the reference's own simd headers (oracle/_ref/libpandora_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libpandora_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libpandora_ref.so")
+MISS = 0xFFFFFFFF
+
+
+class Ray(C.Structure):
+    _fields_ = [("o", C.c_float * 3), ("d", C.c_float * 3), ("tnear", C.c_float), ("tfar", C.c_float)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("idx", C.c_void_p)]
+
+
+class Bvh8(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("leaf_idx", C.c_void_p), ("root", C.c_uint32), ("obj_prim", C.c_void_p), ("mesh", Mesh)]
+
+
+class Svdag(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("root", C.c_uint32), ("bounds_min", C.c_float * 3), ("inv_extent", C.c_float), ("enabled", C.c_int)]
+
+
+class Leaf(C.Structure):
+    _fields_ = [("bvh", Bvh8), ("dag", Svdag)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("root", C.c_uint32), ("leaves", C.c_void_p), ("n_leaves", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "inner_visits", "leaf_pops", "tri_tests")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def ensure_built():
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_build/libpandora_oracle.so"])
+
+
+_orc = None
+_ref = None
+
+
+def oracle() -> C.CDLL:
+    global _orc
+    if _orc is None:
+        ensure_built()
+        _orc = C.CDLL(ORACLE_SO)
+        _orc.orc_svdag_intersect.argtypes = [C.POINTER(Svdag), C.POINTER(Ray), C.c_int]
+        _orc.orc_bvh4_step.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.POINTER(Ray), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p]
+        _orc.orc_tri_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _orc.orc_bvh8_inner.argtypes = [C.c_void_p, C.POINTER(Ray), C.c_void_p, C.c_void_p]
+        _orc.orc_bvh8_inner.restype = C.c_uint
+        _orc.orc_hmin_index4.argtypes = [C.c_void_p]
+        _orc.orc_hmin_index4.restype = C.c_uint
+        _orc.orc_compress_perm8.argtypes = [C.c_uint, C.c_void_p]
+        _orc.orc_bvh8_perm.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        _orc.orc_sign_shift.argtypes = [C.c_float, C.c_float, C.c_float]
+        _orc.orc_sign_shift.restype = C.c_uint32
+        _orc.orc_bvh8_trace.argtypes = [C.POINTER(Bvh8), C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5 + [C.POINTER(Counters), C.c_int]
+        _orc.orc_scene_trace.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(Counters), C.c_int]
+        _orc.orc_brute_trace.argtypes = [C.POINTER(Mesh), C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    return _orc
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def ref() -> C.CDLL:
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+        _ref.ref_bvh8_inner.argtypes = [C.c_void_p, C.POINTER(Ray), C.c_void_p, C.c_void_p]
+        _ref.ref_bvh8_inner.restype = C.c_uint
+        _ref.ref_hmin_index4.argtypes = [C.c_void_p]
+        _ref.ref_hmin_index4.restype = C.c_uint
+        _ref.ref_hmin_index8.argtypes = [C.c_void_p]
+        _ref.ref_hmin_index8.restype = C.c_uint
+        _ref.ref_compress_perm8.argtypes = [C.c_uint, C.c_void_p]
+        _ref.ref_permute8.argtypes = [C.c_void_p] * 3
+        _ref.ref_compress8.argtypes = [C.c_void_p, C.c_uint, C.c_void_p]
+        _ref.ref_minmax8.argtypes = [C.c_void_p] * 4
+        _ref.ref_svdag_intersect.argtypes = [C.POINTER(Svdag), C.POINTER(Ray)]
+        _ref.ref_bvh4_step.argtypes = [C.POINTER(Scene), C.c_int, C.POINTER(Ray), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p]
+        _ref.ref_bvh8_trace.argtypes = [C.POINTER(Bvh8), C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5
+        _ref.ref_scene_trace.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(Counters)]
+    return _ref
+
+
+def make_ray(o, d, tnear=0.0, tfar=3.4028234663852886e38) -> Ray:
+    return Ray((C.c_float * 3)(*o), (C.c_float * 3)(*d), tnear, tfar)
+
+
+class OracleBvh8:
+    """Keeps the numpy arrays alive behind an orc_bvh8."""
+
+    def __init__(self, nodes, leaf_idx, root, prim_ids, pos, idx):
+        self.nodes = np.ascontiguousarray(nodes, np.float32)
+        self.leaf_idx = np.ascontiguousarray(leaf_idx, np.uint32)
+        self.prim_ids = np.ascontiguousarray(prim_ids, np.uint32)
+        self.pos = np.ascontiguousarray(pos, np.float32)
+        self.idx = np.ascontiguousarray(idx, np.uint32)
+        self.c = Bvh8(self.nodes.ctypes.data, self.leaf_idx.ctypes.data, int(root), self.prim_ids.ctypes.data,
+                      Mesh(self.pos.ctypes.data, self.idx.ctypes.data))
+
+    @classmethod
+    def from_host(cls, hb, mesh):
+        return cls(hb.nodes, hb.leaf_idx, hb.root, hb.prim_ids, mesh.pos, mesh.idx)
+
+    def trace(self, rays: np.ndarray, any_hit=False, tri_mode=0, threads=1, use_ref=False):
+        n = rays.shape[1]
+        rays = np.ascontiguousarray(rays, np.float32)
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        obj, hit = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        cnt = Counters()
+        if use_ref:
+            ref().ref_bvh8_trace(C.byref(self.c), int(any_hit), tri_mode, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, u.ctypes.data, v.ctypes.data, hit.ctypes.data)
+        else:
+            oracle().orc_bvh8_trace(C.byref(self.c), int(any_hit), tri_mode, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, u.ctypes.data, v.ctypes.data, hit.ctypes.data, C.byref(cnt), threads)
+        if any_hit:
+            return {"hit": hit, "counters": cnt.as_dict()}
+        return {"t": t, "obj": obj, "u": u, "v": v, "counters": cnt.as_dict()}
+
+
+class OracleScene:
+    """Two-level scene: top BVH4 + per-leaf BVH8 + optional SVDAGs."""
+
+    def __init__(self, top_nodes, root, leaf_bvhs: list[OracleBvh8], dag_words=None, dag_descs=None, leaf_dag=None):
+        self.top_nodes = np.ascontiguousarray(top_nodes, np.float32)
+        self.leaf_bvhs = leaf_bvhs
+        self.dag_words = None if dag_words is None else np.ascontiguousarray(dag_words, np.uint32)
+        self.leaves = (Leaf * len(leaf_bvhs))()
+        for i, b in enumerate(leaf_bvhs):
+            self.leaves[i].bvh = b.c
+            di = None if leaf_dag is None else int(leaf_dag[i])
+            if di is not None and di != MISS and self.dag_words is not None:
+                d = dag_descs[di]
+                self.leaves[i].dag = Svdag(self.dag_words.ctypes.data, int(d["root"]), (C.c_float * 3)(*[float(x) for x in d["bounds_min"]]), float(d["inv_extent"]), 1)
+            else:
+                self.leaves[i].dag = Svdag(0, 0, (C.c_float * 3)(0, 0, 0), 0.0, 0)
+        self.c = Scene(self.top_nodes.ctypes.data, int(root), C.cast(self.leaves, C.c_void_p), len(leaf_bvhs))
+
+    def trace(self, rays: np.ndarray, any_hit=False, tri_mode=0, lanes=3, threads=1, use_ref=False):
+        n = rays.shape[1]
+        rays = np.ascontiguousarray(rays, np.float32)
+        t, u, v = (np.zeros(n, np.float32) for _ in range(3))
+        obj, leaf, hit, visits = (np.zeros(n, np.uint32) for _ in range(4))
+        cnt = Counters()
+        if use_ref:
+            ref().ref_scene_trace(C.byref(self.c), int(any_hit), tri_mode, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, leaf.ctypes.data,
+                                  u.ctypes.data, v.ctypes.data, hit.ctypes.data, visits.ctypes.data, C.byref(cnt))
+        else:
+            oracle().orc_scene_trace(C.byref(self.c), int(any_hit), tri_mode, lanes, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, leaf.ctypes.data,
+                                     u.ctypes.data, v.ctypes.data, hit.ctypes.data, visits.ctypes.data, C.byref(cnt), threads)
+        out = {"visits": visits, "counters": cnt.as_dict()}
+        if any_hit:
+            out["hit"] = hit
+        else:
+            out.update({"t": t, "obj": obj, "leaf": leaf, "u": u, "v": v})
+        return out
+
+
+def brute(mesh, rays: np.ndarray, tri_mode=0, threads=4):
+    n = rays.shape[1]
+    rays = np.ascontiguousarray(rays, np.float32)
+    pos = np.ascontiguousarray(mesh.pos, np.float32)
+    idx = np.ascontiguousarray(mesh.idx, np.uint32)
+    m = Mesh(pos.ctypes.data, idx.ctypes.data)
+    t, prim = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    oracle().orc_brute_trace(C.byref(m), idx.shape[0], tri_mode, rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data, threads)
+    return t, prim

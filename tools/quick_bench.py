@@ -1,0 +1,37 @@
+"""Ad-hoc timing of the single-level kernel (development aid; bench.py is the contract)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import pandora_amd as pa
+
+n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+mesh = pa.scenes.g_atrium()
+t0 = time.time(); hb = pa.accel.build_bvh8(mesh.pos, mesh.idx); print("build %.2fs nodes %d depth %d tris %d" % (time.time() - t0, hb.n_nodes, hb.depth, mesh.n_tris), flush=True)
+ctx = pa.accel.Context(0)
+bvh = ctx.upload_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
+prim = pa.scenes.primary_rays((3, 3, 9), (28, 5, 9), (0, 1, 0), 70, n_side, n_side)
+dprim = torch.from_numpy(prim).cuda()
+ctx.set_stats(True)
+out = ctx.trace_bvh8(bvh, dprim); ctx.sync()
+print("primary: %.3f ms, %.1f Mrays/s" % (ctx.last_kernel_ms(), prim.shape[1] / ctx.last_kernel_ms() / 1e3), ctx.counters(), flush=True)
+t = out["t"].cpu().numpy(); obj = out["obj"].cpu().numpy().view(np.uint32)
+print("primary hit frac", (obj != 0xFFFFFFFF).mean())
+primid = np.where(obj == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), hb.prim_ids[np.minimum(obj, hb.prim_ids.size - 1)])
+diff = pa.scenes.diffuse_bounce_rays(mesh, prim, t, primid)
+ddiff = torch.from_numpy(diff).cuda()
+n = diff.shape[1]
+o2 = ctx.trace_bvh8(bvh, ddiff); ctx.sync()
+print("diffuse (stats on): %.3f ms, %.1f Mrays/s" % (ctx.last_kernel_ms(), n / ctx.last_kernel_ms() / 1e3), ctx.counters(), flush=True)
+ctx.set_stats(False)
+for bpc, chunk in ((4, 64), (4, 32), (4, 256), (2, 64)):
+    ctx.set_tuning(bpc, chunk)
+    ms = []
+    for it in range(5):
+        ctx.trace_bvh8(bvh, ddiff, out=o2); ctx.sync(); ms.append(ctx.last_kernel_ms())
+    print("diffuse bpc=%d chunk=%d: best %.3f ms median %.3f ms -> %.1f Mrays/s" % (bpc, chunk, min(ms), sorted(ms)[2], n / min(ms) / 1e3), flush=True)
+ctx.set_tuning(4, 64)
+ms = []
+for it in range(5):
+    ctx.trace_bvh8(bvh, ddiff, kind=pa.capi.ANY); ctx.sync(); ms.append(ctx.last_kernel_ms())
+print("any-hit diffuse: best %.3f ms -> %.1f Mrays/s" % (min(ms), n / min(ms) / 1e3))
+print("hit frac diffuse", (o2["obj"].cpu().numpy().view(np.uint32) != 0xFFFFFFFF).mean())
