@@ -718,9 +718,12 @@ static void* job_run(void* p)
             continue;
         }
         if (j->any_hit) {
+            uint64_t before = j->c.leaf_visits;
             int hit = j->kind == 0 ? orc_bvh8_intersect_any(j->b, j->tri_mode, &r, &j->c)
                                    : orc_scene_intersect_any(j->s, j->tri_mode, j->lanes, &r, &j->c);
             j->anyhit[i] = (uint32_t)hit;
+            if (j->visits)
+                j->visits[i] = (uint32_t)(j->c.leaf_visits - before);
         } else {
             orc_hit h;
             h.obj = ORC_MISS;

@@ -272,3 +272,50 @@ class Context:
         cnt = capi.Counters()
         _check(self._L.pgpu_get_counters(self._h, C.byref(cnt)), self._h)
         return {f: int(getattr(cnt, f)) for f, _ in capi.Counters._fields_}
+
+
+@dataclass
+class TwoLevelScene:
+    """Host description of the two-level structure the reference's
+    OfflineBatchingAccelerationStructureBuilder produces (offline_batching...h:307-386): batching points
+    (triangle groups), one bottom-level BVH8 and optionally one SVDAG per point, a BVH4 over the points."""
+    groups: list            # per input leaf: uint32 triangle ids
+    bvhs: list              # per input leaf: HostBvh8
+    top: HostBvh4
+    dags: HostSvdags | None
+    leaf_bounds: np.ndarray
+
+    @property
+    def n_leaves(self) -> int:
+        return len(self.groups)
+
+    def upload(self, ctx: "Context", mesh_id: int):
+        """Uploads BVHs, SVDAGs and the top level. Returns bvh ids in final leaf-slot order."""
+        ids = [ctx.upload_bvh8(b, mesh_id) for b in self.bvhs]
+        if self.dags is not None:
+            ctx.upload_svdags(self.dags)
+        leaves = np.empty((self.n_leaves, 2), np.uint32)
+        for slot, src in enumerate(self.top.leaf_order):
+            leaves[slot, 0] = ids[int(src)]
+            leaves[slot, 1] = int(src) if self.dags is not None else capi.NO_SVDAG
+        ctx.upload_top_bvh4(self.top, leaves)
+        return leaves[:, 0].copy()
+
+
+def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4) -> TwoLevelScene:
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    group_of, ng = partition_prims(pos, idx, prims_per_batching_point)
+    order = np.argsort(group_of, kind="stable").astype(np.uint32)
+    counts = np.bincount(group_of, minlength=ng)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    groups = [np.ascontiguousarray(order[starts[g]:starts[g + 1]]) for g in range(ng)]
+    bvhs = [build_bvh8(pos, idx, g, max_leaf) for g in groups]
+    bounds = np.empty((ng, 6), np.float32)
+    for g, prims in enumerate(groups):
+        v = pos[idx[prims].ravel()]
+        bounds[g, :3] = v.min(axis=0)
+        bounds[g, 3:] = v.max(axis=0)
+    top = build_top_bvh4(bounds)
+    dags = build_svdags(pos, idx, groups, svdag_res) if svdag_res > 0 else None
+    return TwoLevelScene(groups, bvhs, top, dags, bounds)

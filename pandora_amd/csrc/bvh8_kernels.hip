@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
     // per-ray state, replicated over the 8 lanes of the group
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
     float hitU = 0, hitV = 0;
-    uint32_t hitObj = PGPU_MISS_ID, shift = 0, rayId = 0, bvhId = 0;
+    uint32_t hitObj = PGPU_MISS_ID, shift = 0, rayId = 0, bvhId = 0, tag = 0;
     const unsigned char* nodes = nullptr;
     const unsigned char* tris = nullptr;
     int sp = 0, hitMark = 0;
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             if (take) {
                 rayId = a.work_ray ? a.work_ray[w] : w;
                 bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
+                tag = a.work_tag ? a.work_tag[w] : 0u;
                 const Bvh8Dev bd = a.bvhs[bvhId];
                 nodes = bd.nodes;
                 tris = bd.tris;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                     a.t_out[rayId] = tfar;
                     if (hitObj != PGPU_MISS_ID) {
                         a.obj_out[rayId] = hitObj;
-                        a.leaf_out[rayId] = bvhId;
+                        a.leaf_out[rayId] = tag;
                         a.u_out[rayId] = hitU;
                         a.v_out[rayId] = hitV;
                     } else if (a.init_miss) {

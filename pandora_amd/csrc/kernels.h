@@ -30,6 +30,7 @@ struct Bvh8TraceArgs {
     const Bvh8Dev* bvhs;
     const uint32_t* work_ray; // work item -> ray id (nullptr: identity)
     const uint32_t* work_bvh; // work item -> bvh id (nullptr: fixed_bvh)
+    const uint32_t* work_tag; // work item -> value stored in leaf_out on a hit (nullptr: 0)
     uint32_t fixed_bvh;
     uint32_t n_work;
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
@@ -62,6 +63,31 @@ struct TopDev {
     const SvdagDev* dags;
     uint32_t root, n_nodes, n_leaves, n_dags;
 };
+
+struct TopTraceArgs {
+    TopDev top;
+    const uint32_t* active; // ray ids to advance (nullptr: identity)
+    uint32_t n_active;
+    const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
+    const float* tfar_state; // closest-hit: current ray.tfar
+    uint32_t* node;          // PauseableBVHInsertHandle.first  (pauseable_bvh.h:8)
+    uint64_t* stack;         // PauseableBVHInsertHandle.second
+    uint32_t* visits;        // may be nullptr
+    uint32_t* any_out;       // any-hit: 1 once occluded
+    uint32_t* parked_count;
+    uint32_t* parked_ray;
+    uint32_t* parked_leaf;
+    uint32_t* leaf_count;
+    unsigned long long* counters; // [0] svdag tests, [1] svdag culled
+};
+
+bool topNodesFitLds(uint32_t nNodes);
+hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream);
+hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, hipStream_t stream);
+hipError_t launchBinByLeaf(const uint32_t* parkedRay, const uint32_t* parkedLeaf, const uint32_t* parkedCount, const uint32_t* leafStart,
+    uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream);
+hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
+    uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);
 
 size_t bvh8TraceLdsBytes();
 hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream);

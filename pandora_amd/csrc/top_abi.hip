@@ -1,20 +1,378 @@
-// Two-level path (top-level PauseableBVH4 + SVDAG early-out + per-leaf BVH8): placeholder entry
-// points until top_kernels.hip lands; they fail loudly instead of pretending.
+// Two-level entry points of the C ABI: SVDAG / top-level upload and the wavefront loop
+//   top-level episode -> bin parked rays by leaf -> per-leaf bottom-level traversal -> resume
+// that replaces the reference's TaskGraph flush loop (task_graph.cpp:19-56) around
+// OfflineBatchingAccelerationStructure (offline_batching_acceleration_structure.h:158-260,406-437).
 #include "context.h"
+#include <algorithm>
+#include <cstring>
+
+using namespace pandora_hip;
+
+namespace {
+
+int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                               \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess)                            \
+            return fail((ctx), PGPU_ERR_HIP, #call, e_); \
+    } while (0)
+
+template <typename T>
+int uploadOwned(pgpu_ctx* c, const T* host, size_t n, T** dev)
+{
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16)));
+    c->owned.push_back(p);
+    if (n)
+        HIP_TRY(c, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T*>(p);
+    return PGPU_OK;
+}
+
+int ensureBuf(pgpu_ctx* c, DeviceBuffer& b, size_t bytes)
+{
+    if (b.bytes >= bytes)
+        return PGPU_OK;
+    if (b.ptr)
+        HIP_TRY(c, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    HIP_TRY(c, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return PGPU_OK;
+}
+
+size_t alignUp(size_t v) { return (v + 255) & ~size_t(255); }
+
+} // namespace
+
 extern "C" {
-int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t*, size_t, const pgpu_svdag_desc*, size_t)
+
+int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags)
 {
-    if (c) c->err = "pgpu_upload_svdags: not built yet";
-    return PGPU_ERR_NO_SCENE;
+    if (!c || !words || !dags || n_words == 0 || n_dags == 0)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: null or empty argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // every offset stored in the array must stay inside it (nodes are read unchecked on the device)
+    for (size_t d = 0; d < n_dags; ++d)
+        if (dags[d].root >= n_words)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: root offset outside the node array");
+    std::vector<uint32_t> todo;
+    std::vector<uint8_t> seen(n_words, 0);
+    for (size_t d = 0; d < n_dags; ++d)
+        todo.push_back(dags[d].root);
+    while (!todo.empty()) {
+        const uint32_t at = todo.back();
+        todo.pop_back();
+        if (seen[at])
+            continue;
+        seen[at] = 1;
+        const uint32_t desc = words[at], inner = ((desc >> 8) & 0xFFu) & ~(desc & 0xFFu);
+        const uint32_t nKids = uint32_t(__builtin_popcount(inner));
+        if (size_t(at) + nKids >= n_words + (nKids ? 0 : 1))
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: child table runs past the node array");
+        for (uint32_t k = 0; k < nKids; ++k) {
+            const uint32_t kid = words[at + 1 + k];
+            if (kid >= n_words)
+                return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: child offset outside the node array");
+            todo.push_back(kid);
+        }
+    }
+    std::vector<SvdagDev> dev(n_dags);
+    for (size_t d = 0; d < n_dags; ++d) {
+        dev[d].root = dags[d].root;
+        for (int a = 0; a < 3; ++a)
+            dev[d].bmin[a] = dags[d].bounds_min[a];
+        dev[d].invExtent = dags[d].inv_extent;
+    }
+    uint32_t* dw = nullptr;
+    SvdagDev* dd = nullptr;
+    int rc = uploadOwned(c, words, n_words, &dw);
+    if (rc != PGPU_OK)
+        return rc;
+    rc = uploadOwned(c, dev.data(), n_dags, &dd);
+    if (rc != PGPU_OK)
+        return rc;
+    c->top.dagWords = dw;
+    c->top.dags = dd;
+    c->top.n_dags = uint32_t(n_dags);
+    return PGPU_OK;
 }
-int pgpu_upload_top_bvh4(pgpu_ctx* c, const void*, size_t, uint32_t, const pgpu_leaf*, size_t)
+
+int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint32_t root, const pgpu_leaf* leaves, size_t n_leaves)
 {
-    if (c) c->err = "pgpu_upload_top_bvh4: not built yet";
-    return PGPU_ERR_NO_SCENE;
+    if (!c || !nodes112 || !leaves || n_nodes == 0 || n_leaves == 0 || root >= n_nodes)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: null or empty argument");
+    if (n_leaves < 2)
+        return fail(c, PGPU_ERR_SINGLE_LEAF, "pgpu_upload_top_bvh4: a single batching point is not supported (pauseable_bvh4.h:180)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const unsigned char* nb = static_cast<const unsigned char*>(nodes112);
+    for (size_t i = 0; i < n_nodes; ++i) {
+        const uint32_t* u = reinterpret_cast<const uint32_t*>(nb + i * 112);
+        const uint32_t bits = u[27], valid = bits & 0xFu, leaf = (bits >> 4) & 0xFu, depth = (bits >> 8) & 0xFFu;
+        if (depth > 15)
+            return fail(c, PGPU_ERR_DEPTH, "pgpu_upload_top_bvh4: node deeper than 15 (64-bit traversal stack)");
+        const uint32_t nInner = uint32_t(__builtin_popcount(valid & ~leaf)), nLeaf = uint32_t(__builtin_popcount(valid & leaf));
+        if ((nInner && size_t(u[24]) + nInner > n_nodes) || (nLeaf && size_t(u[25]) + nLeaf > n_leaves) || u[26] >= n_nodes)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: child, leaf or parent handle out of range");
+    }
+    std::vector<TopLeafDev> lv(n_leaves);
+    for (size_t i = 0; i < n_leaves; ++i) {
+        if (leaves[i].bvh_id >= c->bvhs.size())
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: leaf names an unknown bvh id");
+        if (leaves[i].svdag != PGPU_NO_SVDAG && leaves[i].svdag >= c->top.n_dags)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: leaf names an unknown svdag");
+        lv[i].bvh = leaves[i].bvh_id;
+        lv[i].svdag = leaves[i].svdag;
+    }
+    unsigned char* dn = nullptr;
+    TopLeafDev* dl = nullptr;
+    int rc = uploadOwned(c, nb, n_nodes * 112, &dn);
+    if (rc != PGPU_OK)
+        return rc;
+    rc = uploadOwned(c, lv.data(), n_leaves, &dl);
+    if (rc != PGPU_OK)
+        return rc;
+    c->top.nodes = dn;
+    c->top.leaves = dl;
+    c->top.root = root;
+    c->top.n_nodes = uint32_t(n_nodes);
+    c->top.n_leaves = uint32_t(n_leaves);
+    c->haveTop = true;
+    return PGPU_OK;
 }
-int pgpu_trace(pgpu_ctx* c, int, int, const pgpu_rays*, size_t, int, const pgpu_hits*, uint32_t*, pgpu_counters*, void*)
+
+int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
+    const pgpu_hits* hits, uint32_t* any_hit, pgpu_counters* counters, void* stream_)
 {
-    if (c) c->err = "pgpu_trace: not built yet";
-    return PGPU_ERR_NO_SCENE;
+    if (!c || !rays)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace: null argument");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace: no top-level structure uploaded");
+    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace: kind must be PGPU_CLOSEST or PGPU_ANY");
+    if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace: unknown triangle test");
+    if (mem != PGPU_MEM_HOST && mem != PGPU_MEM_DEVICE)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace: mem must be PGPU_MEM_HOST or PGPU_MEM_DEVICE");
+    if (kind == PGPU_CLOSEST && (!hits || !hits->t || !hits->obj || !hits->leaf || !hits->u || !hits->v))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace: closest-hit needs t, obj, leaf, u, v arrays");
+    if (kind == PGPU_ANY && !any_hit)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace: any-hit needs the any_hit array");
+    if (n > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace: batch too large");
+    const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, rays->tfar };
+    for (const float* p : rp)
+        if (!p && n)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_trace: null ray array");
+    if (counters)
+        std::memset(counters, 0, sizeof(*counters));
+    if (n == 0)
+        return PGPU_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        // syncBvhTable lives in abi.hip; re-upload here if a BVH was added since the last trace
+        if (c->bvhTableDirty) {
+            if (c->bvhTableCap < c->bvhs.size()) {
+                if (c->bvhTable)
+                    HIP_TRY(c, hipFree(c->bvhTable));
+                c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
+                HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
+            }
+            HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
+            c->bvhTableDirty = false;
+        }
+    }
+    hipStream_t stream = (mem == PGPU_MEM_DEVICE && stream_) ? static_cast<hipStream_t>(stream_) : c->stream;
+    const bool wantVisits = hits && hits->visits;
+
+    // ---- carve the work buffer
+    const size_t nl = c->top.n_leaves;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += alignUp(bytes);
+        return at;
+    };
+    const size_t oNode = carve(n * 4), oStack = carve(n * 8), oParkedRay = carve(n * 4), oParkedLeaf = carve(n * 4);
+    const size_t oWorkRay = carve(n * 4), oWorkBvh = carve(n * 4), oWorkLeaf = carve(n * 4);
+    const size_t oLeafCount = carve(nl * 4), oLeafStart = carve(nl * 4), oLeafFill = carve(nl * 4);
+    const size_t oParkedCount = carve(256), oCounters = carve(256);
+    size_t oRays = 0, oHits = 0;
+    if (mem == PGPU_MEM_HOST) {
+        oRays = carve(n * 8 * 4);
+        oHits = carve(n * 7 * 4);
+    }
+    int rc = ensureBuf(c, c->work, off);
+    if (rc != PGPU_OK)
+        return rc;
+    unsigned char* wb = static_cast<unsigned char*>(c->work.ptr);
+    uint32_t* dNode = reinterpret_cast<uint32_t*>(wb + oNode);
+    uint64_t* dStack = reinterpret_cast<uint64_t*>(wb + oStack);
+    uint32_t* dParkedRay = reinterpret_cast<uint32_t*>(wb + oParkedRay);
+    uint32_t* dParkedLeaf = reinterpret_cast<uint32_t*>(wb + oParkedLeaf);
+    uint32_t* dWorkRay = reinterpret_cast<uint32_t*>(wb + oWorkRay);
+    uint32_t* dWorkBvh = reinterpret_cast<uint32_t*>(wb + oWorkBvh);
+    uint32_t* dWorkLeaf = reinterpret_cast<uint32_t*>(wb + oWorkLeaf);
+    uint32_t* dLeafCount = reinterpret_cast<uint32_t*>(wb + oLeafCount);
+    uint32_t* dLeafStart = reinterpret_cast<uint32_t*>(wb + oLeafStart);
+    uint32_t* dLeafFill = reinterpret_cast<uint32_t*>(wb + oLeafFill);
+    uint32_t* dParkedCount = reinterpret_cast<uint32_t*>(wb + oParkedCount);
+    unsigned long long* dCounters = reinterpret_cast<unsigned long long*>(wb + oCounters);
+
+    float* dT = nullptr;
+    uint32_t *dObj = nullptr, *dLeaf = nullptr, *dVisits = nullptr, *dAny = nullptr;
+    float *dU = nullptr, *dV = nullptr;
+    if (mem == PGPU_MEM_HOST) {
+        float* dr = reinterpret_cast<float*>(wb + oRays);
+        for (int i = 0; i < 8; ++i)
+            HIP_TRY(c, hipMemcpyAsync(dr + size_t(i) * n, rp[i], n * 4, hipMemcpyHostToDevice, stream));
+        for (int i = 0; i < 8; ++i)
+            rp[i] = dr + size_t(i) * n;
+        float* dh = reinterpret_cast<float*>(wb + oHits);
+        dT = dh;
+        dObj = reinterpret_cast<uint32_t*>(dh + n);
+        dLeaf = reinterpret_cast<uint32_t*>(dh + 2 * n);
+        dU = dh + 3 * n;
+        dV = dh + 4 * n;
+        dVisits = wantVisits ? reinterpret_cast<uint32_t*>(dh + 5 * n) : nullptr;
+        dAny = reinterpret_cast<uint32_t*>(dh + 6 * n);
+    } else {
+        if (kind == PGPU_CLOSEST) {
+            dT = hits->t;
+            dObj = hits->obj;
+            dLeaf = hits->leaf;
+            dU = hits->u;
+            dV = hits->v;
+        }
+        dVisits = wantVisits ? hits->visits : nullptr;
+        dAny = any_hit;
+    }
+
+    const uint32_t streamBlocks = uint32_t(std::min<size_t>((n + 255) / 256, size_t(c->numCUs) * 8));
+    HIP_TRY(c, hipMemsetAsync(dCounters, 0, 256, stream));
+    if (c->stats)
+        HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    HIP_TRY(c, launchInitState(uint32_t(n), c->top.root, dNode, dStack, rp[7], kind == PGPU_CLOSEST ? dT : nullptr, dObj, dLeaf, dU, dV,
+                   dVisits, kind == PGPU_ANY ? dAny : nullptr, streamBlocks, stream));
+
+    TopTraceArgs ta {};
+    ta.top = c->top;
+    ta.ox = rp[0];
+    ta.oy = rp[1];
+    ta.oz = rp[2];
+    ta.dx = rp[3];
+    ta.dy = rp[4];
+    ta.dz = rp[5];
+    ta.tnear = rp[6];
+    ta.tfar_in = rp[7];
+    ta.tfar_state = dT;
+    ta.node = dNode;
+    ta.stack = dStack;
+    ta.visits = dVisits;
+    ta.any_out = dAny;
+    ta.parked_count = dParkedCount;
+    ta.parked_ray = dParkedRay;
+    ta.parked_leaf = dParkedLeaf;
+    ta.leaf_count = dLeafCount;
+    ta.counters = dCounters;
+
+    Bvh8TraceArgs ba {};
+    ba.bvhs = c->bvhTable;
+    ba.work_ray = dWorkRay;
+    ba.work_bvh = dWorkBvh;
+    ba.work_tag = dWorkLeaf;
+    ba.ox = rp[0];
+    ba.oy = rp[1];
+    ba.oz = rp[2];
+    ba.dx = rp[3];
+    ba.dy = rp[4];
+    ba.dz = rp[5];
+    ba.tnear = rp[6];
+    ba.tfar_in = kind == PGPU_CLOSEST ? dT : rp[7];
+    ba.t_out = dT;
+    ba.obj_out = dObj;
+    ba.leaf_out = dLeaf;
+    ba.u_out = dU;
+    ba.v_out = dV;
+    ba.any_out = dAny;
+    ba.cursor = c->cursor;
+    ba.chunk = c->chunk;
+    ba.init_miss = 0;
+    ba.stats = c->stats ? c->statsDev : nullptr;
+
+    uint64_t rounds = 0, leafVisits = 0;
+    uint32_t nActive = uint32_t(n);
+    const uint32_t* active = nullptr; // round 0: every ray, identity order
+    const uint32_t topMaxBlocks = uint32_t(c->numCUs) * 2u;
+    while (nActive > 0) {
+        HIP_TRY(c, hipMemsetAsync(dParkedCount, 0, 4, stream));
+        HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
+        ta.active = active;
+        ta.n_active = nActive;
+        HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u)), stream));
+        uint32_t parked = 0;
+        HIP_TRY(c, hipMemcpyAsync(&parked, dParkedCount, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        if (parked == 0)
+            break;
+        ++rounds;
+        leafVisits += parked;
+        HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), stream));
+        HIP_TRY(c, launchBinByLeaf(dParkedRay, dParkedLeaf, dParkedCount, dLeafStart, dLeafFill, c->top.leaves, dWorkRay, dWorkBvh, dWorkLeaf,
+                       std::max(1u, std::min(uint32_t(c->numCUs) * 4u, (parked + 255u) / 256u)), stream));
+        HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 4, stream));
+        ba.n_work = parked;
+        const uint32_t blocks = std::max(1u, std::min(uint32_t(c->numCUs * c->blocksPerCU), (parked + 31u) / 32u));
+        HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+        active = dWorkRay;
+        nActive = parked;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+
+    if (mem == PGPU_MEM_HOST) {
+        if (kind == PGPU_CLOSEST) {
+            void* dst[5] = { hits->t, hits->obj, hits->leaf, hits->u, hits->v };
+            const void* src[5] = { dT, dObj, dLeaf, dU, dV };
+            for (int i = 0; i < 5; ++i)
+                HIP_TRY(c, hipMemcpyAsync(dst[i], src[i], n * 4, hipMemcpyDeviceToHost, stream));
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(any_hit, dAny, n * 4, hipMemcpyDeviceToHost, stream));
+        }
+        if (wantVisits)
+            HIP_TRY(c, hipMemcpyAsync(hits->visits, dVisits, n * 4, hipMemcpyDeviceToHost, stream));
+    }
+    unsigned long long cnt[2] = { 0, 0 };
+    HIP_TRY(c, hipMemcpyAsync(cnt, dCounters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
+    c->counters = pgpu_counters {};
+    c->counters.svdag_tests = cnt[0];
+    c->counters.svdag_culled = cnt[1];
+    c->counters.leaf_visits = leafVisits;
+    c->counters.rounds = rounds;
+    if (c->stats) {
+        unsigned long long s[3];
+        HIP_TRY(c, hipMemcpy(s, c->statsDev, sizeof(s), hipMemcpyDeviceToHost));
+        c->counters.inner_visits = s[0];
+        c->counters.leaf_pops = s[1];
+        c->counters.tri_tests = s[2];
+    }
+    if (counters)
+        *counters = c->counters;
+    return PGPU_OK;
 }
 }

@@ -186,3 +186,11 @@ def brute(mesh, rays: np.ndarray, tri_mode=0, threads=4):
     t, prim = np.zeros(n, np.float32), np.zeros(n, np.uint32)
     oracle().orc_brute_trace(C.byref(m), idx.shape[0], tri_mode, rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data, threads)
     return t, prim
+
+
+def scene_from_two_level(tl, mesh) -> OracleScene:
+    """OracleScene for a pandora_amd.accel.TwoLevelScene (leaves in final slot order)."""
+    leaf_bvhs = [OracleBvh8.from_host(tl.bvhs[int(src)], mesh) for src in tl.top.leaf_order]
+    if tl.dags is not None:
+        return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs, tl.dags.words, tl.dags.descs, [int(s) for s in tl.top.leaf_order])
+    return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs)

@@ -1,0 +1,55 @@
+"""GPU parity: two-level path (PauseableBVH4 + SVDAG early-out + per-leaf BVH8) vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pandora_amd as pa
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.asarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module", params=[0, 32], ids=["no_svdag", "svdag32"])
+def two_level(request):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    ctx = pa.accel.Context(0)
+    mesh = pa.scenes.g_small()
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=request.param)
+    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+    yield ctx, mesh, tl, ob.scene_from_two_level(tl, mesh)
+    ctx.close()
+
+
+def _ray_sets(mesh):
+    hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
+    orc = ob.OracleBvh8.from_host(hb, mesh)
+    prim = pa.scenes.primary_rays((0, 1, 3.2), (0, 1, 0), (0, 1, 0), 50, 96, 96)
+    w = orc.trace(prim)
+    diff = pa.scenes.diffuse_bounce_rays(mesh, prim, w["t"], w["obj"])
+    shad = pa.scenes.shadow_rays(mesh, prim, w["t"], w["obj"], (-0.3, 1.99, -0.3), (0.3, 1.99, 0.3))
+    rnd = pa.scenes.random_rays((-3, -1, -3), (3, 3, 3), 5000, seed=3)
+    far = pa.scenes.random_rays((-300, -300, -300), (300, 300, 300), 5000, seed=4, toward=((-1, 0, -1), (1, 2, 1)))
+    return {"primary": prim, "diffuse": diff, "shadow": shad, "random": rnd, "far": far}
+
+
+def test_two_level_matches_oracle(two_level):
+    ctx, mesh, tl, orc = two_level
+    for name, rays in _ray_sets(mesh).items():
+        got, cnt = ctx.trace(rays)
+        want = orc.trace(rays, lanes=3)
+        for k in ("t", "obj", "leaf", "u", "v", "visits"):
+            bad = np.nonzero(_bits(got[k]) != _bits(want[k]))[0]
+            assert bad.size == 0, f"{name}: {k} differs on {bad.size} rays, first {bad[:5]}: got {got[k][bad[:5]]} want {want[k][bad[:5]]}"
+        for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+            assert cnt[k] == want["counters"][k], f"{name}: counter {k}: {cnt[k]} != {want['counters'][k]}"
+        got_any, cnt_any = ctx.trace(rays, kind=pa.capi.ANY)
+        want_any = orc.trace(rays, any_hit=True, lanes=3)
+        assert np.array_equal(_bits(got_any["hit"]), want_any["hit"]), f"{name}: any-hit differs"
+        assert np.array_equal(_bits(got_any["visits"]), want_any["visits"]), f"{name}: any-hit visits differ"
+        for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+            assert cnt_any[k] == want_any["counters"][k], f"{name}: any counter {k}"
