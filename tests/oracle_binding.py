@@ -194,3 +194,60 @@ def scene_from_two_level(tl, mesh) -> OracleScene:
     if tl.dags is not None:
         return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs, tl.dags.words, tl.dags.descs, [int(s) for s in tl.top.leaf_order])
     return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs)
+
+
+# ---------------------------------------------------------------------------- golden fixtures
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+class _Mesh:
+    def __init__(self, pos, idx):
+        self.pos, self.idx = pos, idx
+
+
+class _HostBvh8:
+    def __init__(self, nodes, leaf_idx, root, prim_ids):
+        self.nodes, self.leaf_idx, self.root, self.prim_ids = nodes, leaf_idx, int(root), prim_ids
+        self.n_nodes = int(nodes.shape[0])
+
+
+def load_golden_bvh8():
+    z = np.load(os.path.join(GOLDEN, "bvh8_small.npz"))
+    mesh = _Mesh(z["pos"], z["idx"])
+    hb = _HostBvh8(z["nodes"], z["leaf_idx"], z["root"], z["prim_ids"])
+    return z, mesh, hb, OracleBvh8.from_host(hb, mesh)
+
+
+class _Top:
+    def __init__(self, nodes, root, leaf_order):
+        self.nodes, self.root, self.leaf_order = nodes, int(root), leaf_order
+
+
+class _Dags:
+    def __init__(self, words, descs):
+        self.words, self.descs = words, descs
+
+
+class _TwoLevel:
+    def __init__(self, z):
+        self.n_leaves = int(z["n_leaves"])
+        self.bvhs = [_HostBvh8(z[f"leaf{i}_nodes"], z[f"leaf{i}_leaf_idx"], z[f"leaf{i}_root"], z[f"leaf{i}_prim_ids"]) for i in range(self.n_leaves)]
+        self.top = _Top(z["top_nodes"], z["top_root"], z["leaf_order"])
+        self.dags = _Dags(z["dag_words"], z["dag_descs"])
+
+
+def load_golden_two_level():
+    z = np.load(os.path.join(GOLDEN, "two_level_small.npz"))
+    mesh = _Mesh(z["pos"], z["idx"])
+    tl = _TwoLevel(z)
+    return z, mesh, tl, scene_from_two_level(tl, mesh)
+
+
+def svdag_trace(words, desc, rays, lanes=3, use_ref=False):
+    words = np.ascontiguousarray(words, np.uint32)
+    dag = Svdag(words.ctypes.data, int(desc["root"]), (C.c_float * 3)(*[float(x) for x in desc["bounds_min"]]), float(desc["inv_extent"]), 1)
+    out = np.zeros(rays.shape[1], np.uint8)
+    for i in range(rays.shape[1]):
+        ray = make_ray(rays[0:3, i], rays[3:6, i], float(rays[6, i]), float(rays[7, i]))
+        out[i] = ref().ref_svdag_intersect(C.byref(dag), C.byref(ray)) if use_ref else oracle().orc_svdag_intersect(C.byref(dag), C.byref(ray), lanes)
+    return out

@@ -1,0 +1,181 @@
+"""Host builders (own SAH builder replacing Embree): structural invariants of the emitted trees."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pandora_amd as pa
+
+
+def _walk_bvh8(hb):
+    """yields (node index, depth); checks handles."""
+    nodes_u = hb.nodes.view(np.uint32)
+    seen_nodes, seen_slots = set(), []
+    stack = [(hb.root, 0)]
+    max_depth = 0
+    while stack:
+        h, d = stack.pop()
+        flags, idx = h >> 29, h & 0x1FFFFFFF
+        if flags == 2:
+            assert idx < hb.n_nodes and idx not in seen_nodes
+            seen_nodes.add(idx)
+            max_depth = max(max_depth, d + 1)
+            for c in nodes_u[idx, 48:56]:
+                if c != 0:
+                    stack.append((int(c), d + 1))
+        else:
+            assert flags & 4, "reserved handle flags"
+            cnt = (flags & 3) + 1
+            seen_slots.extend(range(idx, idx + cnt))
+    return seen_nodes, seen_slots, max_depth
+
+
+@pytest.mark.parametrize("max_leaf", [1, 4])
+def test_bvh8_covers_every_primitive_once_and_boxes_enclose_children(max_leaf):
+    mesh = pa.scenes.g_small()
+    hb = pa.accel.build_bvh8(mesh.pos, mesh.idx, max_leaf=max_leaf)
+    nodes, slots, depth = _walk_bvh8(hb)
+    assert len(nodes) == hb.n_nodes
+    assert sorted(slots) == list(range(hb.leaf_idx.size))
+    assert sorted(hb.leaf_idx.tolist()) == list(range(mesh.n_tris))
+    assert depth == hb.depth and 7 * depth + 8 <= 96
+    tri_lo = mesh.pos[mesh.idx].min(axis=1)
+    tri_hi = mesh.pos[mesh.idx].max(axis=1)
+    nu = hb.nodes.view(np.uint32)
+
+    def bounds(h):
+        flags, idx = h >> 29, h & 0x1FFFFFFF
+        if flags == 2:
+            k = [c for c in range(8) if nu[idx, 48 + c] != 0]
+            n = hb.nodes[idx]
+            lo = np.array([n[0:8][k].min(), n[16:24][k].min(), n[32:40][k].min()])
+            hi = np.array([n[8:16][k].max(), n[24:32][k].max(), n[40:48][k].max()])
+            for c in k:  # stored child box == exact bounds of what is below it
+                clo, chi = bounds(int(nu[idx, 48 + c]))
+                assert np.array_equal(np.array([n[c], n[16 + c], n[32 + c]], np.float32), clo.astype(np.float32))
+                assert np.array_equal(np.array([n[8 + c], n[24 + c], n[40 + c]], np.float32), chi.astype(np.float32))
+            return lo, hi
+        cnt = (flags & 3) + 1
+        prims = hb.prim_ids[hb.leaf_idx[idx: idx + cnt]]
+        return tri_lo[prims].min(axis=0), tri_hi[prims].max(axis=0)
+
+    bounds(hb.root)
+
+
+def test_bvh8_octant_permutation_words_follow_the_reference_rule():
+    mesh = pa.scenes.g_small()
+    hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
+    nu = hb.nodes.view(np.uint32)
+    for i in range(hb.n_nodes):
+        n = hb.nodes[i]
+        k = int((nu[i, 48:56] != 0).sum())
+        assert np.all(nu[i, 48: 48 + k] != 0), "children are packed at the front"
+        lo = np.ascontiguousarray(np.stack([n[0:8], n[16:24], n[32:40]], 1), np.float32)
+        hi = np.ascontiguousarray(np.stack([n[8:16], n[24:32], n[40:48]], 1), np.float32)
+        want = np.zeros(8, np.uint32)
+        ob.oracle().orc_bvh8_perm(lo.ctypes.data, hi.ctypes.data, k, want.ctypes.data)
+        assert np.array_equal(nu[i, 56:64], want), i
+        for octant in range(8):  # each octant's 8 slots are a permutation of 0..7
+            assert sorted(((nu[i, 56:64] >> (3 * octant)) & 7).tolist()) == list(range(8))
+        assert np.all(n[0:48].reshape(6, 8)[:, k:] == 0), "absent children are zero boxes (wive_bvh8_build8_impl.h:168-170)"
+
+
+def test_bvh8_single_leaf_root_and_errors():
+    mesh = pa.scenes.grid_patch((0, 0, 0), (1, 0, 0), (0, 1, 0), 1, 1)
+    hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
+    assert hb.n_nodes == 0 and (hb.root >> 29) == (4 | 1)  # leaf handle, 2 primitives
+    orc = ob.OracleBvh8(np.zeros((1, 64), np.float32), hb.leaf_idx, hb.root, hb.prim_ids, mesh.pos, mesh.idx)
+    rays = pa.scenes.pack_rays(np.array([[0.3, 0.3, 1]], np.float32), np.array([[0, 0, -1]], np.float32), np.zeros(1, np.float32), np.full(1, 100, np.float32))
+    assert orc.trace(rays)["t"][0] == 1.0
+    with pytest.raises(pa.capi.PandoraError):
+        pa.accel.build_bvh8(mesh.pos, np.array([[0, 1, 99]], np.uint32))
+    with pytest.raises(pa.capi.PandoraError):
+        pa.accel.build_bvh8(mesh.pos, mesh.idx, max_leaf=5)
+
+
+def test_bvh8_depth_budget_on_degenerate_input():
+    # 40k coincident triangles: SAH cannot separate them; the builder must fall back to balanced cuts
+    n = 40000
+    pos = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (n, 1))
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    hb = pa.accel.build_bvh8(pos, idx)
+    assert hb.depth <= 12
+    _, slots, depth = _walk_bvh8(hb)
+    assert len(slots) == n and depth <= 12
+    # a long thin line of triangles: SAH peels; still bounded
+    pos = np.zeros((3 * n, 3), np.float32)
+    x = (1.5 ** (np.arange(n) % 60)).astype(np.float32) + np.arange(n, dtype=np.float32)
+    pos[0::3, 0], pos[1::3, 0], pos[2::3, 0] = x, x + 0.1, x
+    pos[2::3, 1] = 0.1
+    hb = pa.accel.build_bvh8(pos, idx)
+    assert hb.depth <= 12
+
+
+def test_top_bvh4_layout():
+    rng = np.random.default_rng(3)
+    for n in (2, 3, 4, 5, 17, 300):
+        lo = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+        b = np.concatenate([lo, lo + rng.uniform(0.1, 2, (n, 3)).astype(np.float32)], 1)
+        top = pa.accel.build_top_bvh4(b)
+        assert sorted(top.leaf_order.tolist()) == list(range(n))
+        nu = top.nodes.view(np.uint32)
+        assert top.depth <= 15
+        seen_leaves = []
+        for i in range(top.nodes.shape[0]):
+            bits = int(nu[i, 27])
+            valid, leaf, depth = bits & 15, (bits >> 4) & 15, (bits >> 8) & 255
+            k = bin(valid).count("1")
+            assert valid == (1 << k) - 1 and k >= 2
+            n_inner, n_leaf = bin(valid & ~leaf & 15).count("1"), bin(valid & leaf).count("1")
+            if i == top.root:
+                assert depth == 0
+            for j in range(n_inner):  # DFS-contiguous children, parent / depth links (pauseable_bvh4.h:461-482)
+                c = int(nu[i, 24]) + j
+                assert int(nu[c, 26]) == i and ((int(nu[c, 27]) >> 8) & 255) == depth + 1
+            seen_leaves += list(range(int(nu[i, 25]), int(nu[i, 25]) + n_leaf)) if n_leaf else []
+            slot = 0
+            for c in range(4):  # leaf child boxes equal the input leaf bounds
+                if (valid & leaf) >> c & 1:
+                    src = int(top.leaf_order[int(nu[i, 25]) + slot])
+                    got = np.array([top.nodes[i, c], top.nodes[i, 4 + c], top.nodes[i, 8 + c], top.nodes[i, 12 + c], top.nodes[i, 16 + c], top.nodes[i, 20 + c]])
+                    assert np.array_equal(got, b[src])
+                    slot += 1
+        assert sorted(seen_leaves) == list(range(n))
+    with pytest.raises(pa.capi.PandoraError) as e:
+        pa.accel.build_top_bvh4(np.zeros((1, 6), np.float32))
+    assert e.value.code == pa.capi.ERR_SINGLE_LEAF
+
+
+def test_partition_respects_the_primitive_budget():
+    mesh = pa.scenes.g_small()
+    for budget in (16, 100, 5000):
+        g, ng = pa.accel.partition_prims(mesh.pos, mesh.idx, budget)
+        counts = np.bincount(g, minlength=ng)
+        assert counts.sum() == mesh.n_tris and counts.max() <= budget and counts.min() >= 1
+
+
+def test_svdag_round_trip_and_conservative_voxelisation():
+    mesh = pa.scenes.merge([pa.scenes.icosphere((0, 0, 0), 1.0, 2), pa.scenes.box((1.2, -0.3, -0.3), (1.9, 0.3, 0.3), 1)])
+    prims = np.arange(mesh.n_tris, dtype=np.uint32)
+    for res in (8, 32):
+        grid, bounds = pa.accel.voxelize(mesh.pos, mesh.idx, prims, res)
+        dags = pa.accel.build_svdags(mesh.pos, mesh.idx, [prims], res)
+        back = pa.accel.svdag_expand(dags.words, dags.descs[0])
+        assert np.array_equal(back, grid), "DAG must expand to exactly the voxel grid it was built from"
+        # every triangle vertex and centroid lies in a set voxel (conservative)
+        ext = float((bounds[3:] - bounds[:3]).max())
+        pts = np.concatenate([mesh.pos[mesh.idx].reshape(-1, 3), mesh.pos[mesh.idx].mean(axis=1)])
+        v = np.minimum(((pts - bounds[:3]) * (res / ext)).astype(np.int64), res - 1)
+        lin = (v[:, 2] * res + v[:, 1]) * res + v[:, 0]
+        assert np.all((grid[lin >> 5] >> (lin & 31).astype(np.uint32)) & 1)
+        assert np.isclose(float(dags.descs[0]["inv_extent"]), 1.0 / ext)
+
+
+def test_svdag_sharing_across_groups():
+    a = pa.scenes.icosphere((0, 0, 0), 1.0, 2)
+    mesh = pa.scenes.merge([a, pa.scenes.icosphere((5, 0, 0), 1.0, 2), pa.scenes.icosphere((0, 7, 0), 1.0, 2)])
+    groups = [np.arange(i * a.n_tris, (i + 1) * a.n_tris, dtype=np.uint32) for i in range(3)]
+    dags = pa.accel.build_svdags(mesh.pos, mesh.idx, groups, 32)
+    single = pa.accel.build_svdags(a.pos, a.idx, [np.arange(a.n_tris, dtype=np.uint32)], 32)
+    # three translated copies voxelise (nearly) identically: the merged array is much smaller than 3x
+    assert dags.words.size < 1.5 * single.words.size
+    assert dags.words_before >= 2.5 * single.words.size
