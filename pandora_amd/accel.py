@@ -268,6 +268,9 @@ class Context:
     def set_tuning(self, blocks_per_cu: int, chunk: int):
         _check(self._L.pgpu_set_tuning(self._h, blocks_per_cu, chunk), self._h)
 
+    def set_kernel_variant(self, lanes_per_ray: int, refill_min: int = 2, stack_window: int = 0):
+        _check(self._L.pgpu_set_kernel_variant(self._h, lanes_per_ray, refill_min, stack_window), self._h)
+
     def counters(self) -> dict:
         cnt = capi.Counters()
         _check(self._L.pgpu_get_counters(self._h, C.byref(cnt)), self._h)

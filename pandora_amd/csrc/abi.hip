@@ -1,6 +1,7 @@
 // C-ABI implementation: device context, scene upload, batch tracing. See include/pandora_hip.h.
 #include "context.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -102,11 +103,49 @@ int bvh8Depth(const unsigned char* nodes, size_t nNodes, size_t nIdx, uint32_t r
     return deepest;
 }
 
-struct RayPtrs {
-    const float* p[8];
-};
+// The kernel's fast slab test assumes min <= max and finite bounds for every present child.
+bool bvh8NeedsExact(const unsigned char* nodes, size_t nNodes)
+{
+    for (size_t i = 0; i < nNodes; ++i) {
+        const float* f = reinterpret_cast<const float*>(nodes + i * 256);
+        const uint32_t* kids = reinterpret_cast<const uint32_t*>(f) + 48;
+        for (int c = 0; c < 8; ++c) {
+            if (kids[c] == 0u)
+                continue;
+            for (int a = 0; a < 3; ++a) {
+                const float lo = f[16 * a + c], hi = f[16 * a + 8 + c];
+                if (!(lo <= hi) || !(std::fabs(lo) <= 3.4028234663852886e38f) || !(std::fabs(hi) <= 3.4028234663852886e38f))
+                    return true;
+            }
+        }
+    }
+    return false;
+}
 
 } // namespace
+
+namespace pandora_hip {
+int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks)
+{
+    const uint32_t need = stackEntriesForDepth(depth);
+    const uint32_t window = stackWindow(need, c->lanesPerRay, c->stackWindow);
+    a.stack_entries = window;
+    a.spill_entries = need > window ? need - window : 0u;
+    a.spill = nullptr;
+    const uint32_t raysPerBlock = 4u * (64u / uint32_t(c->lanesPerRay));
+    const uint32_t maxBlocks = uint32_t(c->numCUs) * blocksPerCU(c->blocksPerCU, window, c->lanesPerRay);
+    const uint32_t wantBlocks = uint32_t((n_work + 2 * raysPerBlock - 1) / (2 * raysPerBlock));
+    *blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
+    if (a.spill_entries) {
+        const size_t bytes = size_t(*blocks) * raysPerBlock * a.spill_entries * 8u;
+        const int rc = ensure(c, c->spill, bytes);
+        if (rc != PGPU_OK)
+            return rc;
+        a.spill = static_cast<unsigned long long*>(c->spill.ptr);
+    }
+    return PGPU_OK;
+}
+}
 
 extern "C" {
 
@@ -165,7 +204,7 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipFree(c->cursor);
     if (c->statsDev)
         (void)hipFree(c->statsDev);
-    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work })
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill })
         if (b->ptr)
             (void)hipFree(b->ptr);
     (void)hipEventDestroy(c->ev0);
@@ -187,10 +226,20 @@ int pgpu_set_stats(pgpu_ctx* c, int enabled)
 
 int pgpu_set_tuning(pgpu_ctx* c, int blocks_per_cu, int chunk)
 {
-    if (!c || blocks_per_cu < 1 || blocks_per_cu > 8 || chunk < 8 || chunk > 65536)
+    if (!c || blocks_per_cu < 0 || blocks_per_cu > 8 || chunk < 8 || chunk > 65536)
         return PGPU_ERR_INVALID;
     c->blocksPerCU = blocks_per_cu;
     c->chunk = uint32_t(chunk);
+    return PGPU_OK;
+}
+
+int pgpu_set_kernel_variant(pgpu_ctx* c, int lanes_per_ray, int refill_min, int stack_window)
+{
+    if (!c || (lanes_per_ray != 4 && lanes_per_ray != 8) || refill_min < 1 || refill_min > 16 || stack_window < 0 || stack_window > 96)
+        return PGPU_ERR_INVALID;
+    c->lanesPerRay = lanes_per_ray;
+    c->refillMin = uint32_t(refill_min);
+    c->stackWindow = stack_window;
     return PGPU_OK;
 }
 
@@ -267,6 +316,7 @@ int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const ui
     d.n_nodes = uint32_t(n_nodes);
     d.n_slots = uint32_t(n_indices);
     d.depth = uint32_t(depth);
+    d.needs_exact = bvh8NeedsExact(static_cast<const unsigned char*>(nodes256), n_nodes) ? 1u : 0u;
     c->bvhs.push_back(d);
     c->bvhTableDirty = true;
     *bvh_id = uint32_t(c->bvhs.size() - 1);
@@ -353,16 +403,18 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
     a.cursor = c->cursor;
     a.chunk = c->chunk;
     a.init_miss = 1;
+    a.refill_min = c->refillMin;
     a.stats = c->stats ? c->statsDev : nullptr;
 
     HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
     if (c->stats)
         HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
-    const uint32_t maxBlocks = uint32_t(c->numCUs * c->blocksPerCU);
-    const uint32_t wantBlocks = uint32_t((n + 31) / 32); // 32 rays in flight per 256-thread block
-    const uint32_t blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
+    uint32_t blocks = 1;
+    rc = pandora_hip::planBvh8Launch(c, c->bvhs[bvh_id].depth, n, a, &blocks);
+    if (rc != PGPU_OK)
+        return rc;
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
-    HIP_TRY(c, launchBvh8Trace(a, kind, tri_mode, c->stats, blocks, stream));
+    HIP_TRY(c, launchBvh8Trace(a, kind, tri_mode, c->stats, c->lanesPerRay, blocks, stream));
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
 
     if (mem == PGPU_MEM_HOST) {

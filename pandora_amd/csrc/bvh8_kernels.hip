@@ -31,10 +31,13 @@ namespace pandora_hip {
 namespace {
 
 constexpr uint32_t kWavesPerBlock = 4;
-constexpr uint32_t kStageBytesPerWave = 2048;          // 8 rays x 256 B
-constexpr uint32_t kStackEntries = 96;                 // wive_bvh8_impl.h:74-75
-constexpr uint32_t kStackStride = kStackEntries * 8 + 64; // +64 B: odd groups start 16 banks later
-constexpr uint32_t kLdsBytes = kWavesPerBlock * kStageBytesPerWave + kWavesPerBlock * 8 * kStackStride;
+// Per-ray stack: the reference reserves 96 entries (wive_bvh8_impl.h:74-75); a tree with d nested inner
+// nodes never holds more than 7 d + 8, so the launch sizes the LDS stack from the deepest uploaded tree
+// (more blocks per CU for shallow trees). +64 B per ray: odd ray groups start 16 banks later.
+__host__ __device__ constexpr uint32_t stackStrideBytes(uint32_t entries)
+{
+    return (entries * 8u + 64u) % 128u == 0u ? entries * 8u + 32u : entries * 8u + 64u;
+}
 
 __device__ __forceinline__ float min86(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float max86(float a, float b) { return a > b ? a : b; }
@@ -152,48 +155,91 @@ __device__ __forceinline__ TriHit triWatertight(float ox, float oy, float oz, fl
     return r;
 }
 
-template <bool ANY, int TRI, bool STATS>
+// LPR = lanes per ray: 8 (one child per lane, the reference's ymm mapping) or 4 (two children per lane,
+// 16 rays per wave: the per-ray bookkeeping and the leaf phase are amortised over twice as many rays).
+template <int LPR>
+struct Geo {
+    static constexpr uint32_t G = 64 / LPR;      // ray groups per wave
+    static constexpr uint32_t CPL = 8 / LPR;     // children per lane
+    static constexpr uint32_t NDMA = 16 / LPR;   // LDS-DMA instructions per 256-byte node
+    static constexpr uint32_t kStage = G * 256;  // staging bytes per wave
+    static constexpr uint32_t kOrder = CPL > 1 ? G * 64 : 0; // child-ordering scratch per wave
+    static constexpr uint64_t kOneBitPerGroup = LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+    static constexpr uint32_t kGroupMask = (1u << LPR) - 1u;
+    // swizzle of the 16-byte piece position inside one DMA instruction's region, chosen so that the ray groups
+    // of one LDS lane group read disjoint banks (LPR 8: ds_read_b32, 32 banks; LPR 4: ds_read_b64, 64 banks)
+    __device__ static uint32_t swz(uint32_t g) { return LPR == 8 ? ((g & 3u) << 1) : (((g >> 2) & 1u) << 1); }
+    // LDS byte offset (inside the wave's staging area) of 16-byte piece P of group g's node / triangle block
+    __device__ static uint32_t pieceAt(uint32_t g, uint32_t P) { return (P / LPR) * 1024u + (g * LPR + ((P % LPR) ^ swz(g))) * 16u; }
+};
+
+template <int LPR, bool ANY, int TRI, bool STATS>
 __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
 {
-    __shared__ __align__(16) unsigned char lds[kLdsBytes];
+    using GE = Geo<LPR>;
+    constexpr uint32_t G = GE::G, CPL = GE::CPL;
+    static_assert(LPR == 8 || LPR == 4, "lanes per ray");
+    extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t g = lane >> 3, k = lane & 7u;
-    const uint32_t s = g & 3u; // piece swizzle: groups of one half-wave read disjoint LDS banks
-    unsigned char* const stage = lds + wave * kStageBytesPerWave;
-    uint2* const stack = reinterpret_cast<uint2*>(lds + kWavesPerBlock * kStageBytesPerWave + (wave * 8u + g) * kStackStride);
-    const uint32_t groupShift = g * 8u;
-    const uint64_t oneBitPerGroup = 0x0101010101010101ull;
+    const uint32_t g = lane / LPR, q = lane % LPR;
+    unsigned char* const stage = lds + wave * GE::kStage;
+    uint2* const order = reinterpret_cast<uint2*>(lds + kWavesPerBlock * GE::kStage + wave * GE::kOrder + g * 64u);
+    uint2* const stack = reinterpret_cast<uint2*>(lds + kWavesPerBlock * (GE::kStage + GE::kOrder) + (wave * G + g) * stackStrideBytes(a.stack_entries));
+    const uint32_t groupShift = g * LPR;
+    // Only the first stack_entries entries of a ray's stack live in LDS; deeper ones (rare: the window is
+    // sized for the common case so that more blocks fit a CU) go to a per-group slice of a global spill
+    // buffer, written and read with agent-scope accesses so that the lanes of the group see each other's
+    // entries.
+    const uint32_t W = a.stack_entries;
+    unsigned long long* const spill = a.spill ? a.spill + (size_t(blockIdx.x * kWavesPerBlock + wave) * G + g) * a.spill_entries : nullptr;
+    auto stackStore = [&](int idx, uint2 v) {
+        if (uint32_t(idx) < W) {
+            stack[idx] = v;
+        } else {
+            __hip_atomic_store(&spill[uint32_t(idx) - W], (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto stackLoad = [&](int idx) {
+        if (uint32_t(idx) < W)
+            return stack[idx];
+        const unsigned long long v = __hip_atomic_load(&spill[uint32_t(idx) - W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2(uint32_t(v), uint32_t(v >> 32));
+    };
 
-    // LDS read addresses of this lane: child k of node array j (minX,maxX,minY,maxY | minZ,maxZ,children,perm)
+    // LDS read offsets of this lane: children q*CPL .. q*CPL+CPL-1 of node array j
+    // (minX,maxX,minY,maxY,minZ,maxZ,children,perm; array j = bytes [32 j, 32 j + 32) of the node)
     const unsigned char* nodeRd[8];
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j)
-        nodeRd[j] = stage + (j >> 2) * 1024u + g * 128u + (((j & 3u) ^ s) * 32u) + k * 4u;
-    // triangle k of a leaf: 16-byte pieces 3k, 3k+1, 3k+2
+        nodeRd[j] = stage + GE::pieceAt(g, 2u * j + ((q * CPL * 4u) >> 4)) + ((q * CPL * 4u) & 15u);
+    // triangle (q & 3) of a leaf: 16-byte pieces 3t, 3t+1, 3t+2
     const unsigned char* triRd[3];
 #pragma unroll
-    for (uint32_t j = 0; j < 3; ++j) {
-        const uint32_t p = 3u * (k & 3u) + j;
-        triRd[j] = stage + (p >> 3) * 1024u + (g * 8u + ((p & 7u) ^ (s << 1))) * 16u;
-    }
-    const uint32_t myPiece = k ^ (s << 1); // which 16-byte piece of each 128-byte half this lane fetches
+    for (uint32_t j = 0; j < 3; ++j)
+        triRd[j] = stage + GE::pieceAt(g, 3u * (q & 3u) + j);
+    const uint32_t myPiece = q ^ GE::swz(g); // piece (within each DMA instruction's LPR pieces) this lane fetches
 
-    // per-ray state, replicated over the 8 lanes of the group
+    // per-ray state, replicated over the lanes of the group
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
     float hitU = 0, hitV = 0;
     uint32_t hitObj = PGPU_MISS_ID, shift = 0, rayId = 0, bvhId = 0, tag = 0;
     const unsigned char* nodes = nullptr;
     const unsigned char* tris = nullptr;
     int sp = 0, hitMark = 0;
-    bool active = false;
+    bool active = false, exact = false;
+    const unsigned char *rdNearX = nodeRd[0], *rdFarX = nodeRd[1], *rdNearY = nodeRd[2], *rdFarY = nodeRd[3], *rdNearZ = nodeRd[4], *rdFarZ = nodeRd[5];
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     bool exhausted = false;
     uint32_t statInner = 0, statLeaf = 0, statTri = 0;
 
     for (;;) {
         // ------------------------------------------------------------ refill idle groups
-        const uint64_t idle = __ballot(!active) & oneBitPerGroup;
-        if (idle != 0 && !exhausted) {
+        const uint64_t idle = __ballot(!active) & GE::kOneBitPerGroup;
+        const uint32_t nIdle = __popcll(idle);
+        // a refill pass costs a full trip through the ray-setup code for the whole wave: wait until a few
+        // groups are idle (or nothing else is left to do) so that one pass serves several rays
+        if (!exhausted && (nIdle >= a.refill_min || nIdle == G)) {
             if (chunkNext >= chunkEnd) {
                 uint32_t c = 0;
                 if (lane == 0)
@@ -206,11 +252,10 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                     chunkEnd = chunkNext;
                 }
             }
-            const uint32_t need = __popcll(idle);
             const uint32_t rank = __popcll(idle & ((1ull << groupShift) - 1ull));
             const uint32_t w = chunkNext + rank;
             const bool take = !active && w < chunkEnd;
-            chunkNext = min(chunkNext + need, chunkEnd);
+            chunkNext = min(chunkNext + nIdle, chunkEnd);
             if (take) {
                 rayId = a.work_ray ? a.work_ray[w] : w;
                 bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
@@ -230,9 +275,20 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                 iy = 1.0f / dy;
                 iz = 1.0f / dz;
                 shift = ((dx > 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dz > 0 ? 4u : 0u)) * 3u; // :384-388
+                // rays that can meet 0 * inf (or carry inf/NaN themselves) take the x86-exact slab test
+                const float big = 3.4028234663852886e38f;
+                const bool tame = fabsf(ix) <= big && fabsf(iy) <= big && fabsf(iz) <= big && ix != 0.0f && iy != 0.0f && iz != 0.0f
+                    && fabsf(ox) <= big && fabsf(oy) <= big && fabsf(oz) <= big && tnear == tnear && tfar == tfar;
+                exact = !tame || bd.needs_exact != 0u;
+                rdNearX = ix < 0.0f ? nodeRd[1] : nodeRd[0];
+                rdFarX = ix < 0.0f ? nodeRd[0] : nodeRd[1];
+                rdNearY = iy < 0.0f ? nodeRd[3] : nodeRd[2];
+                rdFarY = iy < 0.0f ? nodeRd[2] : nodeRd[3];
+                rdNearZ = iz < 0.0f ? nodeRd[5] : nodeRd[4];
+                rdFarZ = iz < 0.0f ? nodeRd[4] : nodeRd[5];
                 hitObj = PGPU_MISS_ID;
                 hitU = hitV = 0.0f;
-                if (k == 0)
+                if (q == 0)
                     stack[0] = make_uint2(bd.root, __float_as_uint(0.0f)); // :80-82
                 sp = 1;
                 hitMark = 0;
@@ -247,24 +303,24 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             continue;
         }
 
-        // ------------------------------------------------------------ pop: 8 top entries at once
+        // ------------------------------------------------------------ pop: the top LPR entries at once
         uint32_t handle = 0;
         bool have = false;
         {
-            const int e = sp - 1 - int(k);
+            const int e = sp - 1 - int(q);
             uint2 ent = make_uint2(0u, 0u);
             if (active && e >= 0)
-                ent = stack[e];
+                ent = stackLoad(e);
             const bool ok = active && e >= 0 && (e >= hitMark || __uint_as_float(ent.y) < tfar);
-            const uint32_t gb = uint32_t(__ballot(ok) >> groupShift) & 0xFFu;
+            const uint32_t gb = uint32_t(__ballot(ok) >> groupShift) & GE::kGroupMask;
             const uint32_t first = gb != 0 ? uint32_t(__builtin_ctz(gb)) : 0u;
-            handle = uint32_t(__builtin_amdgcn_ds_bpermute(int((lane - k + first) << 2), int(ent.x)));
+            handle = uint32_t(__builtin_amdgcn_ds_bpermute(int((lane - q + first) << 2), int(ent.x)));
             if (active) {
                 if (gb != 0) {
                     sp = sp - 1 - int(first);
                     have = true;
                 } else {
-                    sp = max(sp - 8, 0); // all 8 candidates were culled
+                    sp = max(sp - LPR, 0); // every candidate was culled
                 }
                 hitMark = min(hitMark, sp);
             }
@@ -279,41 +335,100 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
         {
             const unsigned char* base = isInner ? nodes + size_t(index) * 256u : tris + size_t(index) * 48u;
             const uint32_t pieces = isInner ? 16u : 3u * count;
-            if (have && myPiece < pieces)
-                ldsDma16(base + myPiece * 16u, stage);
-            if (have && myPiece + 8u < pieces)
-                ldsDma16(base + 128u + myPiece * 16u, stage + 1024u);
+#pragma unroll
+            for (uint32_t h = 0; h < GE::NDMA; ++h)
+                if (have && h * LPR + myPiece < pieces)
+                    ldsDma16(base + (h * LPR + myPiece) * 16u, stage + h * 1024u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 
-        // ------------------------------------------------------------ inner node: slab test of child k
+        // ------------------------------------------------------------ inner node: slab test of this lane's children
         if (isInner) {
-            const float lox = ldsF(nodeRd[0]), hix = ldsF(nodeRd[1]);
-            const float loy = ldsF(nodeRd[2]), hiy = ldsF(nodeRd[3]);
-            const float loz = ldsF(nodeRd[4]), hiz = ldsF(nodeRd[5]);
-            const uint32_t child = ldsU(nodeRd[6]);
-            const uint32_t perm = ldsU(nodeRd[7]);
-            const float tx1 = (lox - ox) * ix, tx2 = (hix - ox) * ix; // :212-217
-            const float ty1 = (loy - oy) * iy, ty2 = (hiy - oy) * iy;
-            const float tz1 = (loz - oz) * iz, tz2 = (hiz - oz) * iz;
-            const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
-            const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
-            const float tmin = max86(tnear, max86(txMin, max86(tyMin, tzMin))); // :224
-            const float tmax = min86(tfar, min86(txMax, min86(tyMax, tzMax)));  // :225
-            const bool overlap = tmin <= tmax;                                   // :233
-            // slot k takes the child named by the octant permutation (:229-232,235)
-            const uint32_t src = (lane - k) + ((perm >> shift) & 7u);
-            const uint32_t pChild = uint32_t(__builtin_amdgcn_ds_bpermute(int(src << 2), int(overlap ? child : 0xFFFFFFFFu)));
-            const float pTmin = __int_as_float(__builtin_amdgcn_ds_bpermute(int(src << 2), __float_as_int(tmin)));
-            const bool keep = pChild != 0xFFFFFFFFu;
-            // compress (:234-237): rank among the kept slots of this group
-            const uint32_t gb = uint32_t(__ballot(keep) >> groupShift) & 0xFFu;
-            const uint32_t rank = __popc(gb & ((1u << k) - 1u));
-            if (keep)
-                stack[sp + int(rank)] = make_uint2(pChild, __float_as_uint(pTmin));
-            sp += int(__popc(gb));
+            float tmin[CPL], tmax[CPL];
+            uint32_t child[CPL], perm[CPL];
+            float nX[CPL], fX[CPL], nY[CPL], fY[CPL], nZ[CPL], fZ[CPL];
+            const bool slow = __ballot(exact) != 0;
+#pragma unroll
+            for (uint32_t i = 0; i < CPL; ++i) {
+                child[i] = ldsU(nodeRd[6] + 4u * i);
+                perm[i] = ldsU(nodeRd[7] + 4u * i);
+            }
+            if (!slow) {
+                // No ray of this wave can produce a NaN (finite non-zero 1/d, finite origin, ordered boxes), so
+                // min(t1,t2) is the plane on the ray's near side: picked through the LDS address (rdNear/rdFar,
+                // set per ray from the sign of 1/d), and the max/min chains are plain IEEE max3/min3.
+#pragma unroll
+                for (uint32_t i = 0; i < CPL; ++i) {
+                    nX[i] = ldsF(rdNearX + 4u * i);
+                    fX[i] = ldsF(rdFarX + 4u * i);
+                    nY[i] = ldsF(rdNearY + 4u * i);
+                    fY[i] = ldsF(rdFarY + 4u * i);
+                    nZ[i] = ldsF(rdNearZ + 4u * i);
+                    fZ[i] = ldsF(rdFarZ + 4u * i);
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < CPL; ++i) {
+                    const float tnx = (nX[i] - ox) * ix, tfx = (fX[i] - ox) * ix;
+                    const float tny = (nY[i] - oy) * iy, tfy = (fY[i] - oy) * iy;
+                    const float tnz = (nZ[i] - oz) * iz, tfz = (fZ[i] - oz) * iz;
+                    tmin[i] = fmaxf(tnear, fmaxf(fmaxf(tnx, tny), tnz));
+                    tmax[i] = fminf(tfar, fminf(fminf(tfx, tfy), tfz));
+                }
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < CPL; ++i) {
+                    const float lox = ldsF(nodeRd[0] + 4u * i), hix = ldsF(nodeRd[1] + 4u * i);
+                    const float loy = ldsF(nodeRd[2] + 4u * i), hiy = ldsF(nodeRd[3] + 4u * i);
+                    const float loz = ldsF(nodeRd[4] + 4u * i), hiz = ldsF(nodeRd[5] + 4u * i);
+                    const float tx1 = (lox - ox) * ix, tx2 = (hix - ox) * ix; // :212-217
+                    const float ty1 = (loy - oy) * iy, ty2 = (hiy - oy) * iy;
+                    const float tz1 = (loz - oz) * iz, tz2 = (hiz - oz) * iz;
+                    const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
+                    const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
+                    tmin[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin))); // :224
+                    tmax[i] = min86(tfar, min86(txMax, min86(tyMax, tzMax)));  // :225
+                }
+            }
+            // slot j (far -> near) takes the child named by the octant permutation (:229-232,235); a child that
+            // fails tmin <= tmax (:233) travels as 0xFFFFFFFF
+            uint32_t pChild[CPL];
+            float pTmin[CPL];
+            if (CPL == 1) {
+                const uint32_t src = (lane - q) + ((perm[0] >> shift) & 7u);
+                pChild[0] = uint32_t(__builtin_amdgcn_ds_bpermute(int(src << 2), int(tmin[0] <= tmax[0] ? child[0] : 0xFFFFFFFFu)));
+                pTmin[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(int(src << 2), __float_as_int(tmin[0])));
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < CPL; ++i)
+                    order[q * CPL + i] = make_uint2(tmin[i] <= tmax[i] ? child[i] : 0xFFFFFFFFu, __float_as_uint(tmin[i]));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t i = 0; i < CPL; ++i) {
+                    const uint2 e = order[(perm[i] >> shift) & 7u];
+                    pChild[i] = e.x;
+                    pTmin[i] = __uint_as_float(e.y);
+                }
+            }
+            // compress (:234-237): rank of every kept slot among the kept slots of this ray, slot order
+            uint32_t rank = 0, total = 0;
+            bool keep[CPL];
+#pragma unroll
+            for (uint32_t i = 0; i < CPL; ++i) {
+                keep[i] = pChild[i] != 0xFFFFFFFFu;
+                const uint32_t gb = uint32_t(__ballot(keep[i]) >> groupShift) & GE::kGroupMask;
+                rank += __popc(gb & ((1u << q) - 1u));
+                total += __popc(gb);
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < CPL; ++i) {
+                if (keep[i])
+                    stackStore(sp + int(rank), make_uint2(pChild[i], __float_as_uint(pTmin[i])));
+                rank += keep[i] ? 1u : 0u;
+            }
+            sp += int(total);
             if (STATS)
-                statInner += (k == 0);
+                statInner += (q == 0);
         }
 
         // ------------------------------------------------------------ leaf: <= 4 triangles, one per lane
@@ -322,7 +437,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             th.hit = false;
             th.t = th.u = th.v = 0.0f;
             uint32_t obj = 0;
-            if (k < count) {
+            if (q < count) {
                 const float4 p0 = *reinterpret_cast<const float4*>(triRd[0]);
                 const float4 p1 = *reinterpret_cast<const float4*>(triRd[1]);
                 const float4 p2 = *reinterpret_cast<const float4*>(triRd[2]);
@@ -333,7 +448,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                     statTri += 1;
             }
             if (STATS)
-                statLeaf += (k == 0);
+                statLeaf += (q == 0);
             // The reference tests the leaf's objects in order, each seeing the tfar left by the previous
             // one and accepting t <= tfar (:272-280). The survivor of that sequence is the LAST object
             // whose t equals the minimum of the valid t's.
@@ -344,10 +459,10 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             const uint32_t gb = uint32_t(__ballot(winner) >> groupShift) & 0xFu;
             if (gb != 0) {
                 const uint32_t w = 31u - __builtin_clz(gb);
-                const int srcAddr = int((lane - k + w) << 2);
+                const int srcAddr = int((lane - q + w) << 2);
                 if (ANY) {
                     // :193-196: first hit ends the ray
-                    if (k == 0)
+                    if (q == 0)
                         a.any_out[rayId] = 1u;
                     active = false;
                     sp = 0;
@@ -363,7 +478,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
 
         // ------------------------------------------------------------ retire rays whose stack ran dry
         if (active && sp == 0) {
-            if (k == 0) {
+            if (q == 0) {
                 if (ANY) {
                     if (a.init_miss)
                         a.any_out[rayId] = 0u;
@@ -384,6 +499,8 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             }
             active = false;
         }
+        if (!active)
+            exact = false;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -397,13 +514,20 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
 
 } // namespace
 
-size_t bvh8TraceLdsBytes() { return kLdsBytes; }
+size_t bvh8TraceLdsBytes(uint32_t stackEntries, int lanesPerRay)
+{
+    const uint32_t groups = 64u / uint32_t(lanesPerRay);
+    const uint32_t order = lanesPerRay == 8 ? 0u : groups * 64u;
+    return kWavesPerBlock * (groups * 256u + order) + kWavesPerBlock * groups * stackStrideBytes(stackEntries);
+}
 
-hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
+template <int LPR>
+static hipError_t launchLpr(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
 {
     const dim3 grid(blocks), block(256);
+    const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries, LPR);
 #define PANDORA_LAUNCH(ANYV, TRIV, STATV) \
-    hipLaunchKernelGGL((bvh8TraceKernel<ANYV, TRIV, STATV>), grid, block, 0, stream, args)
+    hipLaunchKernelGGL((bvh8TraceKernel<LPR, ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args)
     if (kind == PGPU_ANY_ID) {
         if (triMode == PGPU_TRI_WATERTIGHT_ID) {
             if (stats) PANDORA_LAUNCH(true, 1, true); else PANDORA_LAUNCH(true, 1, false);
@@ -419,6 +543,11 @@ hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, boo
     }
 #undef PANDORA_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, int lanesPerRay, uint32_t blocks, hipStream_t stream)
+{
+    return lanesPerRay == 4 ? launchLpr<4>(args, kind, triMode, stats, blocks, stream) : launchLpr<8>(args, kind, triMode, stats, blocks, stream);
 }
 
 } // namespace pandora_hip

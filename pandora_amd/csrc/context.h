@@ -23,8 +23,12 @@ struct pgpu_ctx {
     std::string err;
     float lastKernelMs = 0.0f;
     bool stats = false;
-    int blocksPerCU = 4;
+    int blocksPerCU = 0; // 0 = as many as LDS / registers allow
     uint32_t chunk = 64;
+    int lanesPerRay = 4;     // 8 or 4, see bvh8_kernels.hip
+    uint32_t refillMin = 2;
+    int stackWindow = 0;     // LDS stack entries per ray, 0 = automatic
+    DeviceBuffer spill;      // global overflow of the per-ray stacks
 
     std::vector<HostMesh> meshes;
     std::vector<pandora_hip::Bvh8Dev> bvhs; // host mirror of the device table
@@ -45,3 +49,9 @@ struct pgpu_ctx {
     bool haveTop = false;
     DeviceBuffer work; // per-ray traversal state + queues, grown on demand
 };
+
+namespace pandora_hip {
+// Fills the stack window / spill fields of a bottom-level launch for trees of the given depth and returns
+// the grid size for n_work items (abi.hip).
+int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
+}

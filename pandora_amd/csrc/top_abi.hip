@@ -312,6 +312,10 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ba.cursor = c->cursor;
     ba.chunk = c->chunk;
     ba.init_miss = 0;
+    ba.refill_min = c->refillMin;
+    uint32_t deepest = 0;
+    for (const Bvh8Dev& b : c->bvhs)
+        deepest = std::max(deepest, b.depth);
     ba.stats = c->stats ? c->statsDev : nullptr;
 
     uint64_t rounds = 0, leafVisits = 0;
@@ -336,8 +340,11 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                        std::max(1u, std::min(uint32_t(c->numCUs) * 4u, (parked + 255u) / 256u)), stream));
         HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 4, stream));
         ba.n_work = parked;
-        const uint32_t blocks = std::max(1u, std::min(uint32_t(c->numCUs * c->blocksPerCU), (parked + 31u) / 32u));
-        HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+        uint32_t blocks = 1;
+        rc = planBvh8Launch(c, deepest, parked, ba, &blocks);
+        if (rc != PGPU_OK)
+            return rc;
+        HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, c->lanesPerRay, blocks, stream));
         active = dWorkRay;
         nActive = parked;
     }

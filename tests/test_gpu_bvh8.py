@@ -36,9 +36,13 @@ def _ray_sets(mesh, orc, res=96):
     return {"primary": prim, "diffuse": diff, "shadow": shad, "random": rnd}
 
 
+# (lanes per ray, refill threshold, LDS stack window): window 0 = automatic, a small window forces most of
+# the stack through the global spill buffer
+@pytest.mark.parametrize("lanes_per_ray,refill_min,window", [(8, 1, 0), (4, 2, 0), (4, 5, 0), (4, 2, 4), (8, 2, 4), (4, 2, 1)])
 @pytest.mark.parametrize("tri_mode", [pa.capi.TRI_MT, pa.capi.TRI_WATERTIGHT])
-def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode):
+def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode, lanes_per_ray, refill_min, window):
     mesh, hb, bvh, orc = small
+    gpu_ctx.set_kernel_variant(lanes_per_ray, refill_min, window)
     for name, rays in _ray_sets(mesh, orc).items():
         got = gpu_ctx.trace_bvh8(bvh, rays, tri_mode=tri_mode)
         want = orc.trace(rays, tri_mode=tri_mode)
@@ -46,3 +50,4 @@ def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode):
         got_any = gpu_ctx.trace_bvh8(bvh, rays, kind=pa.capi.ANY, tri_mode=tri_mode)["hit"]
         want_any = orc.trace(rays, any_hit=True, tri_mode=tri_mode)["hit"]
         assert np.array_equal(got_any, want_any), f"{name}: any-hit differs"
+    gpu_ctx.set_kernel_variant(4, 2, 0)

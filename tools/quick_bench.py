@@ -23,13 +23,15 @@ n = diff.shape[1]
 o2 = ctx.trace_bvh8(bvh, ddiff); ctx.sync()
 print("diffuse (stats on): %.3f ms, %.1f Mrays/s" % (ctx.last_kernel_ms(), n / ctx.last_kernel_ms() / 1e3), ctx.counters(), flush=True)
 ctx.set_stats(False)
-for bpc, chunk in ((4, 64), (4, 32), (4, 256), (2, 64)):
+for lpr, rmin, bpc, chunk, win in ((8, 2, 0, 64, 0), (8, 2, 0, 64, 24), (8, 2, 0, 64, 16), (4, 2, 0, 64, 0), (4, 2, 0, 64, 96), (4, 2, 0, 64, 32), (4, 2, 0, 64, 24), (4, 2, 0, 64, 16), (4, 2, 0, 64, 12), (4, 3, 0, 64, 0), (4, 4, 0, 64, 0), (4, 2, 4, 64, 0), (4, 2, 3, 64, 0), (4, 2, 0, 128, 0)):
+    ctx.set_kernel_variant(lpr, rmin, win)
     ctx.set_tuning(bpc, chunk)
     ms = []
     for it in range(5):
         ctx.trace_bvh8(bvh, ddiff, out=o2); ctx.sync(); ms.append(ctx.last_kernel_ms())
-    print("diffuse bpc=%d chunk=%d: best %.3f ms median %.3f ms -> %.1f Mrays/s" % (bpc, chunk, min(ms), sorted(ms)[2], n / min(ms) / 1e3), flush=True)
-ctx.set_tuning(4, 64)
+    print("diffuse lpr=%d refill_min=%d bpc=%d chunk=%d win=%d: best %.3f ms median %.3f ms -> %.1f Mrays/s" % (lpr, rmin, bpc, chunk, win, min(ms), sorted(ms)[2], n / min(ms) / 1e3), flush=True)
+ctx.set_kernel_variant(4, 2, 0)
+ctx.set_tuning(0, 64)
 ms = []
 for it in range(5):
     ctx.trace_bvh8(bvh, ddiff, kind=pa.capi.ANY); ctx.sync(); ms.append(ctx.last_kernel_ms())
