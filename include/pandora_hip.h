@@ -150,6 +150,8 @@ typedef struct {
     uint64_t leaf_visits;               /* rays parked at batching points, summed */
     uint64_t rounds;                    /* wavefront rounds the two-level loop needed */
     uint64_t inner_visits, leaf_pops, tri_tests; /* filled only when stats are enabled */
+    uint64_t wave_steps, leaf_passes, refill_passes; /* kernel-loop diagnostics (stats enabled): wavefront iterations,
+                                                       * those that ran the triangle code, those that fetched new rays */
 } pgpu_counters;
 
 /* WiVeBVH8::intersect / intersectAny over a batch (wive_bvh8_impl.h:57-201): single-level, in-core.
@@ -174,9 +176,10 @@ int pgpu_set_stats(pgpu_ctx*, int enabled);
 int pgpu_get_counters(pgpu_ctx*, pgpu_counters* out);
 int pgpu_set_tuning(pgpu_ctx*, int blocks_per_cu, int chunk); /* blocks_per_cu 0 = automatic */
 /* Bottom-level kernel mapping: lanes per ray (8 = one child per lane, 4 = two children per lane, default),
- * how many ray groups of a wave must be idle before new rays are fetched, and how many entries of each
- * ray's traversal stack stay in LDS (0 = automatic; deeper entries spill to HBM). Results do not depend on it. */
-int pgpu_set_kernel_variant(pgpu_ctx*, int lanes_per_ray, int refill_min, int stack_window);
+ * how many ray groups of a wave must be idle before new rays are fetched, how many entries of each ray's
+ * traversal stack stay in LDS (0 = automatic; deeper entries spill to HBM), and how many rays of a wave must
+ * wait at a leaf before the wave runs its triangle code (0 = automatic). Results do not depend on any of it. */
+int pgpu_set_kernel_variant(pgpu_ctx*, int lanes_per_ray, int refill_min, int stack_window, int leaf_min);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ class Hits(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "rounds", "inner_visits", "leaf_pops", "tri_tests")]
+    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "rounds", "inner_visits", "leaf_pops", "tri_tests", "wave_steps", "leaf_passes", "refill_passes")]
 
 
 class LeafObj(C.Structure):
@@ -86,7 +86,7 @@ SYMBOLS = {
     "pgpu_set_stats": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "pgpu_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "pgpu_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "pgpu_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

@@ -125,11 +125,26 @@ bool bvh8NeedsExact(const unsigned char* nodes, size_t nNodes)
 } // namespace
 
 namespace pandora_hip {
+int readKernelStats(pgpu_ctx* c)
+{
+    unsigned long long s[6];
+    HIP_TRY(c, hipMemcpy(s, c->statsDev, sizeof(s), hipMemcpyDeviceToHost));
+    c->counters.inner_visits = s[0];
+    c->counters.leaf_pops = s[1];
+    c->counters.tri_tests = s[2];
+    c->counters.wave_steps = s[3];
+    c->counters.leaf_passes = s[4];
+    c->counters.refill_passes = s[5];
+    return PGPU_OK;
+}
+
 int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks)
 {
     const uint32_t need = stackEntriesForDepth(depth);
     const uint32_t window = stackWindow(need, c->lanesPerRay, c->stackWindow);
     a.stack_entries = window;
+    a.refill_min = c->refillMin;
+    a.leaf_min = c->leafMin ? c->leafMin : (c->lanesPerRay == 4 ? 4u : 2u);
     a.spill_entries = need > window ? need - window : 0u;
     a.spill = nullptr;
     const uint32_t raysPerBlock = 4u * (64u / uint32_t(c->lanesPerRay));
@@ -233,10 +248,12 @@ int pgpu_set_tuning(pgpu_ctx* c, int blocks_per_cu, int chunk)
     return PGPU_OK;
 }
 
-int pgpu_set_kernel_variant(pgpu_ctx* c, int lanes_per_ray, int refill_min, int stack_window)
+int pgpu_set_kernel_variant(pgpu_ctx* c, int lanes_per_ray, int refill_min, int stack_window, int leaf_min)
 {
-    if (!c || (lanes_per_ray != 4 && lanes_per_ray != 8) || refill_min < 1 || refill_min > 16 || stack_window < 0 || stack_window > 96)
+    if (!c || (lanes_per_ray != 4 && lanes_per_ray != 8) || refill_min < 1 || refill_min > 16 || stack_window < 0 || stack_window > 96
+        || leaf_min < 0 || leaf_min > 16)
         return PGPU_ERR_INVALID;
+    c->leafMin = uint32_t(leaf_min);
     c->lanesPerRay = lanes_per_ray;
     c->refillMin = uint32_t(refill_min);
     c->stackWindow = stack_window;
@@ -403,7 +420,6 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
     a.cursor = c->cursor;
     a.chunk = c->chunk;
     a.init_miss = 1;
-    a.refill_min = c->refillMin;
     a.stats = c->stats ? c->statsDev : nullptr;
 
     HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
@@ -430,12 +446,10 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
         HIP_TRY(c, hipStreamSynchronize(stream));
         HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
         if (c->stats) {
-            unsigned long long s[3];
-            HIP_TRY(c, hipMemcpy(s, c->statsDev, sizeof(s), hipMemcpyDeviceToHost));
             c->counters = pgpu_counters {};
-            c->counters.inner_visits = s[0];
-            c->counters.leaf_pops = s[1];
-            c->counters.tri_tests = s[2];
+            const int rs = pandora_hip::readKernelStats(c);
+            if (rs != PGPU_OK)
+                return rs;
         }
     }
     return PGPU_OK;
@@ -452,11 +466,9 @@ int pgpu_sync(pgpu_ctx* c, void* stream_)
     if (hipEventQuery(c->ev1) == hipSuccess)
         (void)hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1);
     if (c->stats) {
-        unsigned long long s[3];
-        HIP_TRY(c, hipMemcpy(s, c->statsDev, sizeof(s), hipMemcpyDeviceToHost));
-        c->counters.inner_visits = s[0];
-        c->counters.leaf_pops = s[1];
-        c->counters.tri_tests = s[2];
+        const int rs = pandora_hip::readKernelStats(c);
+        if (rs != PGPU_OK)
+            return rs;
     }
     return PGPU_OK;
 }

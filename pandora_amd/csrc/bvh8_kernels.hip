@@ -228,10 +228,12 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
     const unsigned char* tris = nullptr;
     int sp = 0, hitMark = 0;
     bool active = false, exact = false;
+    bool pend = false;   // a leaf has been popped (handle) but not intersected yet
+    uint32_t handle = 0; // last popped stack entry
     const unsigned char *rdNearX = nodeRd[0], *rdFarX = nodeRd[1], *rdNearY = nodeRd[2], *rdFarY = nodeRd[3], *rdNearZ = nodeRd[4], *rdFarZ = nodeRd[5];
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     bool exhausted = false;
-    uint32_t statInner = 0, statLeaf = 0, statTri = 0;
+    uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
 
     for (;;) {
         // ------------------------------------------------------------ refill idle groups
@@ -294,6 +296,8 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                 hitMark = 0;
                 active = true;
             }
+            if (STATS)
+                statRefill += (lane == 0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -304,32 +308,42 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
         }
 
         // ------------------------------------------------------------ pop: the top LPR entries at once
-        uint32_t handle = 0;
-        bool have = false;
+        // A ray that popped a leaf keeps the handle and sits out (pend) until the wave runs a leaf pass: the
+        // triangle code is long, so it runs once several rays of the wave wait for it (or nothing else is
+        // left to do) rather than in every step for the one or two rays that happen to be at a leaf.
+        const bool popNow = active && !pend;
+        bool isInner = false;
         {
             const int e = sp - 1 - int(q);
             uint2 ent = make_uint2(0u, 0u);
-            if (active && e >= 0)
+            if (popNow && e >= 0)
                 ent = stackLoad(e);
-            const bool ok = active && e >= 0 && (e >= hitMark || __uint_as_float(ent.y) < tfar);
+            const bool ok = popNow && e >= 0 && (e >= hitMark || __uint_as_float(ent.y) < tfar);
             const uint32_t gb = uint32_t(__ballot(ok) >> groupShift) & GE::kGroupMask;
             const uint32_t first = gb != 0 ? uint32_t(__builtin_ctz(gb)) : 0u;
-            handle = uint32_t(__builtin_amdgcn_ds_bpermute(int((lane - q + first) << 2), int(ent.x)));
-            if (active) {
+            const uint32_t popped = uint32_t(__builtin_amdgcn_ds_bpermute(int((lane - q + first) << 2), int(ent.x)));
+            if (popNow) {
                 if (gb != 0) {
                     sp = sp - 1 - int(first);
-                    have = true;
+                    handle = popped;
+                    isInner = (popped >> 29) == 2u;
+                    pend = !isInner;
                 } else {
                     sp = max(sp - LPR, 0); // every candidate was culled
                 }
                 hitMark = min(hitMark, sp);
             }
         }
-
-        const bool isInner = have && (handle >> 29) == 2u;
-        const bool isLeaf = have && !isInner;
+        const uint64_t pendMask = __ballot(pend);
+        const bool leafPass = pendMask != 0 && (uint32_t(__popcll(pendMask & GE::kOneBitPerGroup)) >= a.leaf_min || __ballot(isInner) == 0);
+        const bool isLeaf = pend && leafPass;
+        const bool have = isInner || isLeaf;
         const uint32_t index = handle & 0x1FFFFFFFu;
         const uint32_t count = ((handle >> 29) & 3u) + 1u; // :378-382
+        if (STATS) {
+            statIter += (lane == 0);
+            statLeafPass += (lane == 0 && leafPass);
+        }
 
         // ------------------------------------------------------------ fetch node / leaf triangles into LDS
         {
@@ -474,10 +488,11 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                     hitMark = sp; // everything still on the stack predates this hit
                 }
             }
+            pend = false;
         }
 
         // ------------------------------------------------------------ retire rays whose stack ran dry
-        if (active && sp == 0) {
+        if (active && sp == 0 && !pend) {
             if (q == 0) {
                 if (ANY) {
                     if (a.init_miss)
@@ -509,6 +524,11 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
         atomicAdd(&a.stats[0], (unsigned long long)statInner);
         atomicAdd(&a.stats[1], (unsigned long long)statLeaf);
         atomicAdd(&a.stats[2], (unsigned long long)statTri);
+        if (lane == 0) {
+            atomicAdd(&a.stats[3], (unsigned long long)statIter);
+            atomicAdd(&a.stats[4], (unsigned long long)statLeafPass);
+            atomicAdd(&a.stats[5], (unsigned long long)statRefill);
+        }
     }
 }
 

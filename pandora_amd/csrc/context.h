@@ -26,7 +26,8 @@ struct pgpu_ctx {
     int blocksPerCU = 0; // 0 = as many as LDS / registers allow
     uint32_t chunk = 64;
     int lanesPerRay = 4;     // 8 or 4, see bvh8_kernels.hip
-    uint32_t refillMin = 2;
+    uint32_t refillMin = 3;
+    uint32_t leafMin = 0; // 0: automatic
     int stackWindow = 0;     // LDS stack entries per ray, 0 = automatic
     DeviceBuffer spill;      // global overflow of the per-ray stacks
 
@@ -53,5 +54,6 @@ struct pgpu_ctx {
 namespace pandora_hip {
 // Fills the stack window / spill fields of a bottom-level launch for trees of the given depth and returns
 // the grid size for n_work items (abi.hip).
+int readKernelStats(pgpu_ctx* c);
 int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
 }

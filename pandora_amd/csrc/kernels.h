@@ -48,6 +48,7 @@ struct Bvh8TraceArgs {
     uint32_t spill_entries; // entries per ray group in the global spill buffer (0: the window holds the worst case)
     unsigned long long* spill;
     uint32_t refill_min;    // refill idle ray groups once this many are idle
+    uint32_t leaf_min;      // run the leaf (triangle) pass once this many ray groups of the wave wait for it
     unsigned long long* stats;
 };
 
@@ -105,7 +106,7 @@ inline uint32_t stackEntriesForDepth(uint32_t depth)
 // 6 (8 lanes per ray) or 5 (4 lanes per ray) blocks fit a CU; deeper entries spill to global memory.
 inline uint32_t stackWindow(uint32_t need, int lanesPerRay, int requested)
 {
-    const uint32_t cap = requested > 0 ? uint32_t(requested) : (lanesPerRay == 4 ? 20u : 64u);
+    const uint32_t cap = requested > 0 ? uint32_t(requested) : (lanesPerRay == 4 ? 12u : 64u);
     return need < cap ? need : cap;
 }
 // blocks of 256 threads per CU: requested, or (0) as many as LDS (160 KiB) and registers (<= 80 VGPR -> 6) allow

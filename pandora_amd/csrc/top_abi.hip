@@ -312,7 +312,6 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ba.cursor = c->cursor;
     ba.chunk = c->chunk;
     ba.init_miss = 0;
-    ba.refill_min = c->refillMin;
     uint32_t deepest = 0;
     for (const Bvh8Dev& b : c->bvhs)
         deepest = std::max(deepest, b.depth);
@@ -372,11 +371,9 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     c->counters.leaf_visits = leafVisits;
     c->counters.rounds = rounds;
     if (c->stats) {
-        unsigned long long s[3];
-        HIP_TRY(c, hipMemcpy(s, c->statsDev, sizeof(s), hipMemcpyDeviceToHost));
-        c->counters.inner_visits = s[0];
-        c->counters.leaf_pops = s[1];
-        c->counters.tri_tests = s[2];
+        const int rs = readKernelStats(c);
+        if (rs != PGPU_OK)
+            return rs;
     }
     if (counters)
         *counters = c->counters;
