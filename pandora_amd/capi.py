@@ -86,7 +86,7 @@ SYMBOLS = {
     "pgpu_set_stats": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "pgpu_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "pgpu_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pgpu_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

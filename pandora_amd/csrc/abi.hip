@@ -141,14 +141,14 @@ int readKernelStats(pgpu_ctx* c)
 int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks)
 {
     const uint32_t need = stackEntriesForDepth(depth);
-    const uint32_t window = stackWindow(need, c->lanesPerRay, c->stackWindow);
+    const uint32_t window = stackWindow(need, c->stackWindow);
     a.stack_entries = window;
     a.refill_min = c->refillMin;
-    a.leaf_min = c->leafMin ? c->leafMin : (c->lanesPerRay == 4 ? 4u : 2u);
+    a.leaf_min = c->leafMin ? c->leafMin : 4u;
     a.spill_entries = need > window ? need - window : 0u;
     a.spill = nullptr;
-    const uint32_t raysPerBlock = 4u * (64u / uint32_t(c->lanesPerRay));
-    const uint32_t maxBlocks = uint32_t(c->numCUs) * blocksPerCU(c->blocksPerCU, window, c->lanesPerRay);
+    const uint32_t raysPerBlock = 64u; // 4 waves x 16 rays
+    const uint32_t maxBlocks = uint32_t(c->numCUs) * blocksPerCU(c->blocksPerCU, window);
     const uint32_t wantBlocks = uint32_t((n_work + 2 * raysPerBlock - 1) / (2 * raysPerBlock));
     *blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
     if (a.spill_entries) {
@@ -248,13 +248,12 @@ int pgpu_set_tuning(pgpu_ctx* c, int blocks_per_cu, int chunk)
     return PGPU_OK;
 }
 
-int pgpu_set_kernel_variant(pgpu_ctx* c, int lanes_per_ray, int refill_min, int stack_window, int leaf_min)
+int pgpu_set_kernel_variant(pgpu_ctx* c, int refill_min, int stack_window, int leaf_min)
 {
-    if (!c || (lanes_per_ray != 4 && lanes_per_ray != 8) || refill_min < 1 || refill_min > 16 || stack_window < 0 || stack_window > 96
+    if (!c || refill_min < 1 || refill_min > 16 || stack_window < 0 || stack_window > 96
         || leaf_min < 0 || leaf_min > 16)
         return PGPU_ERR_INVALID;
     c->leafMin = uint32_t(leaf_min);
-    c->lanesPerRay = lanes_per_ray;
     c->refillMin = uint32_t(refill_min);
     c->stackWindow = stack_window;
     return PGPU_OK;
@@ -430,7 +429,7 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
     if (rc != PGPU_OK)
         return rc;
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
-    HIP_TRY(c, launchBvh8Trace(a, kind, tri_mode, c->stats, c->lanesPerRay, blocks, stream));
+    HIP_TRY(c, launchBvh8Trace(a, kind, tri_mode, c->stats, blocks, stream));
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
 
     if (mem == PGPU_MEM_HOST) {

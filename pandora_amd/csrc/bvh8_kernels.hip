@@ -42,15 +42,6 @@ __host__ __device__ constexpr uint32_t stackStrideBytes(uint32_t entries)
 __device__ __forceinline__ float min86(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float max86(float a, float b) { return a > b ? a : b; }
 
-__device__ __forceinline__ void ldsDma16(const unsigned char* gsrc, unsigned char* ldsWaveBase)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-        (__attribute__((address_space(3))) void*)ldsWaveBase, 16, 0, 0);
-}
-
-__device__ __forceinline__ float ldsF(const unsigned char* p) { return *reinterpret_cast<const float*>(p); }
-__device__ __forceinline__ uint32_t ldsU(const unsigned char* p) { return *reinterpret_cast<const uint32_t*>(p); }
-
 struct TriHit {
     float t, u, v;
     bool hit;
@@ -155,98 +146,154 @@ __device__ __forceinline__ TriHit triWatertight(float ox, float oy, float oz, fl
     return r;
 }
 
-// LPR = lanes per ray: 8 (one child per lane, the reference's ymm mapping) or 4 (two children per lane,
-// 16 rays per wave: the per-ray bookkeeping and the leaf phase are amortised over twice as many rays).
-template <int LPR>
-struct Geo {
-    static constexpr uint32_t G = 64 / LPR;      // ray groups per wave
-    static constexpr uint32_t CPL = 8 / LPR;     // children per lane
-    static constexpr uint32_t NDMA = 16 / LPR;   // LDS-DMA instructions per 256-byte node
-    static constexpr uint32_t kStage = G * 256;  // staging bytes per wave
-    static constexpr uint32_t kOrder = CPL > 1 ? G * 64 : 0; // child-ordering scratch per wave
-    static constexpr uint64_t kOneBitPerGroup = LPR == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
-    static constexpr uint32_t kGroupMask = (1u << LPR) - 1u;
-    // swizzle of the 16-byte piece position inside one DMA instruction's region, chosen so that the ray groups
-    // of one LDS lane group read disjoint banks (LPR 8: ds_read_b32, 32 banks; LPR 4: ds_read_b64, 64 banks)
-    __device__ static uint32_t swz(uint32_t g) { return LPR == 8 ? ((g & 3u) << 1) : (((g >> 2) & 1u) << 1); }
-    // LDS byte offset (inside the wave's staging area) of 16-byte piece P of group g's node / triangle block
-    __device__ static uint32_t pieceAt(uint32_t g, uint32_t P) { return (P / LPR) * 1024u + (g * LPR + ((P % LPR) ^ swz(g))) * 16u; }
-};
+// ---------------------------------------------------------------------------------------------------
+// Wave layout: a wave64 carries 16 rays, one per quad of lanes (DPP quad_perm moves data inside a quad for
+// free). Lane q of a quad owns children 2q and 2q+1 of the node its ray visits and triangle q of its leaf.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kRaysPerWave = 16;
+constexpr uint32_t kStagePerWave = kRaysPerWave * 256u; // one 256-byte node per ray
+constexpr uint64_t kQuadLane0 = 0x1111111111111111ull;
+constexpr uint64_t kQuadLane3 = 0x8888888888888888ull;
 
-template <int LPR, bool ANY, int TRI, bool STATS>
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// value of lane `(lane & ~3) | perm[lane & 3]` (v_*_dpp quad_perm: folded into the consuming VALU instruction)
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ int quadPerm(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);
+}
+template <int K>
+__device__ __forceinline__ float quadBcast(float v) { return __int_as_float(quadPerm<K, K, K, K>(__float_as_int(v))); }
+__device__ __forceinline__ uint32_t quadOr(uint32_t v)
+{
+    v |= uint32_t(quadPerm<1, 0, 3, 2>(int(v)));
+    v |= uint32_t(quadPerm<2, 3, 0, 1>(int(v)));
+    return v;
+}
+__device__ __forceinline__ uint32_t quadAdd(uint32_t v)
+{
+    v += uint32_t(quadPerm<1, 0, 3, 2>(int(v)));
+    v += uint32_t(quadPerm<2, 3, 0, 1>(int(v)));
+    return v;
+}
+__device__ __forceinline__ float quadMin(float v)
+{
+    v = fminf(v, __int_as_float(quadPerm<1, 0, 3, 2>(__float_as_int(v))));
+    v = fminf(v, __int_as_float(quadPerm<2, 3, 0, 1>(__float_as_int(v))));
+    return v;
+}
+
+// The LDS side of a global_load_lds is M0 + immediate offset + lane * 16 (measured: tools/dma_probe.hip): the
+// immediate offset moves the global AND the LDS address. Piece group h of a node (64 bytes further in memory)
+// must land 1024 bytes further in LDS, so the LDS base handed over is 960 h below the wanted one.
+template <int H>
+__device__ __forceinline__ void nodeDma(const unsigned char* gsrc, __attribute__((address_space(3))) unsigned char* stageUniform)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)(stageUniform + H * 960), 16, H * 64, 0);
+}
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ f2 ldsF2(const lds_u8* p) { return *reinterpret_cast<const __attribute__((address_space(3))) f2*>(p); }
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 ldsU2(const lds_u8* p)
+{
+    const u2v v = *reinterpret_cast<const __attribute__((address_space(3))) u2v*>(p);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void ldsStoreU2(lds_u8* p, uint2 v)
+{
+    u2v w;
+    w.x = v.x;
+    w.y = v.y;
+    *reinterpret_cast<__attribute__((address_space(3))) u2v*>(p) = w;
+}
+__device__ __forceinline__ void ldsStoreU4(lds_u8* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+    u4v r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    r.w = w;
+    *reinterpret_cast<__attribute__((address_space(3))) u4v*>(p) = r;
+}
+
+template <bool ANY, int TRI, bool STATS>
 __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
 {
-    using GE = Geo<LPR>;
-    constexpr uint32_t G = GE::G, CPL = GE::CPL;
-    static_assert(LPR == 8 || LPR == 4, "lanes per ray");
-    extern __shared__ __align__(16) unsigned char lds[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t g = lane / LPR, q = lane % LPR;
-    unsigned char* const stage = lds + wave * GE::kStage;
-    uint2* const order = reinterpret_cast<uint2*>(lds + kWavesPerBlock * GE::kStage + wave * GE::kOrder + g * 64u);
-    uint2* const stack = reinterpret_cast<uint2*>(lds + kWavesPerBlock * (GE::kStage + GE::kOrder) + (wave * G + g) * stackStrideBytes(a.stack_entries));
-    const uint32_t groupShift = g * LPR;
-    // Only the first stack_entries entries of a ray's stack live in LDS; deeper ones (rare: the window is
-    // sized for the common case so that more blocks fit a CU) go to a per-group slice of a global spill
-    // buffer, written and read with agent-scope accesses so that the lanes of the group see each other's
-    // entries.
+    extern __shared__ __align__(16) unsigned char ldsGeneric[];
+    lds_u8* const lds = (lds_u8*)ldsGeneric;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+    const uint32_t g = lane >> 2, q = lane & 3u;
     const uint32_t W = a.stack_entries;
-    unsigned long long* const spill = a.spill ? a.spill + (size_t(blockIdx.x * kWavesPerBlock + wave) * G + g) * a.spill_entries : nullptr;
-    auto stackStore = [&](int idx, uint2 v) {
-        if (uint32_t(idx) < W) {
-            stack[idx] = v;
+
+    // LDS: [4 waves x 16 rays x 256 B node staging][4 waves x 16 rays x stack window]
+    lds_u8* const stageU = lds + wave * kStagePerWave; // wave-uniform
+    // 16-byte piece P of ray g's node sits at (P / 4) * 1024 + (g * 4 + ((P % 4) ^ swz)) * 16 with swz = 2 for the
+    // quads 4..7 and 12..15: a lane reads its children pair (8 bytes of each 32-byte array) with ds_read_b64 and
+    // the two halves of the wave then cover all 64 banks exactly once.
+    const uint32_t swz = ((g >> 2) & 1u) << 1;
+    lds_u8* const pairEven = stageU + g * 64u + q * 8u + (swz ? 32u : 0u); // arrays minX, minY, minZ, children (+1024 each)
+    lds_u8* const pairOdd = stageU + g * 64u + q * 8u + (swz ? 0u : 32u);  // arrays maxX, maxY, maxZ, permutation
+    // after the bounds have been read, the 64 bytes of the ray's minX/maxX arrays hold the 8 (child, tmin) slots
+    lds_u8* const orderBase = stageU + g * 64u;
+    lds_u8* const stackBase = lds + kWavesPerBlock * kStagePerWave + (wave * kRaysPerWave + g) * stackStrideBytes(W);
+    unsigned long long* const spill = a.spill ? a.spill + (size_t(blockIdx.x * kWavesPerBlock + wave) * kRaysPerWave + g) * a.spill_entries : nullptr;
+    const uint32_t myPiece16 = (q ^ swz) * 16u; // the 16-byte piece (of every 64) this lane fetches
+    const uint32_t qbit = 1u << q;
+    const uint32_t quadLane0x4 = (lane & ~3u) << 2;
+
+    auto stackStore = [&](uint32_t idx, uint2 v) {
+        if (idx < W) {
+            ldsStoreU2(stackBase + idx * 8u, v);
         } else {
-            __hip_atomic_store(&spill[uint32_t(idx) - W], (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&spill[idx - W], (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
-    auto stackLoad = [&](int idx) {
-        if (uint32_t(idx) < W)
-            return stack[idx];
-        const unsigned long long v = __hip_atomic_load(&spill[uint32_t(idx) - W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto stackLoad = [&](uint32_t idx) {
+        if (idx < W)
+            return ldsU2(stackBase + idx * 8u);
+        const unsigned long long v = __hip_atomic_load(&spill[idx - W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return make_uint2(uint32_t(v), uint32_t(v >> 32));
     };
 
-    // LDS read offsets of this lane: children q*CPL .. q*CPL+CPL-1 of node array j
-    // (minX,maxX,minY,maxY,minZ,maxZ,children,perm; array j = bytes [32 j, 32 j + 32) of the node)
-    const unsigned char* nodeRd[8];
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j)
-        nodeRd[j] = stage + GE::pieceAt(g, 2u * j + ((q * CPL * 4u) >> 4)) + ((q * CPL * 4u) & 15u);
-    // triangle (q & 3) of a leaf: 16-byte pieces 3t, 3t+1, 3t+2
-    const unsigned char* triRd[3];
-#pragma unroll
-    for (uint32_t j = 0; j < 3; ++j)
-        triRd[j] = stage + GE::pieceAt(g, 3u * (q & 3u) + j);
-    const uint32_t myPiece = q ^ GE::swz(g); // piece (within each DMA instruction's LPR pieces) this lane fetches
+    // refill: lane q of a quad loads component q of the origin and of the direction (lane 3: tnear, tfar)
+    const float* const loadA = q == 0 ? a.ox : (q == 1 ? a.oy : (q == 2 ? a.oz : a.tnear));
+    const float* const loadB = q == 0 ? a.dx : (q == 1 ? a.dy : (q == 2 ? a.dz : a.tfar_in));
 
-    // per-ray state, replicated over the lanes of the group
+    // per-ray state, replicated over the 4 lanes of the quad
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
     float hitU = 0, hitV = 0;
-    uint32_t hitObj = PGPU_MISS_ID, shift = 0, rayId = 0, bvhId = 0, tag = 0;
-    const unsigned char* nodes = nullptr;
-    const unsigned char* tris = nullptr;
+    uint32_t hitObj = PGPU_MISS_ID, shift = 0, rayId = 0, tag = 0, handle = 0;
+    const unsigned char* nodePiece = nullptr; // nodes + this lane's piece offset
+    const unsigned char* triMine = nullptr;   // tris + q * 48: triangle q of leaf slot 0
     int sp = 0, hitMark = 0;
-    bool active = false, exact = false;
-    bool pend = false;   // a leaf has been popped (handle) but not intersected yet
-    uint32_t handle = 0; // last popped stack entry
-    const unsigned char *rdNearX = nodeRd[0], *rdFarX = nodeRd[1], *rdNearY = nodeRd[2], *rdFarY = nodeRd[3], *rdNearZ = nodeRd[4], *rdFarZ = nodeRd[5];
+    // 0 idle, 1 traversing, 2 waiting at a popped leaf (handle) for the wave's next leaf pass, 3 (inside one step
+    // only) popped an inner node (handle)
+    int st = 0;
+    uint32_t exact = 0; // 1: this ray needs the x86-exact slab test
+    const lds_u8 *rdNearX = pairEven, *rdFarX = pairOdd, *rdNearY = pairEven, *rdFarY = pairOdd, *rdNearZ = pairEven, *rdFarZ = pairOdd;
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     bool exhausted = false;
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
 
-    for (;;) {
-        // ------------------------------------------------------------ refill idle groups
-        const uint64_t idle = __ballot(!active) & GE::kOneBitPerGroup;
-        const uint32_t nIdle = __popcll(idle);
-        // a refill pass costs a full trip through the ray-setup code for the whole wave: wait until a few
-        // groups are idle (or nothing else is left to do) so that one pass serves several rays
-        if (!exhausted && (nIdle >= a.refill_min || nIdle == G)) {
+    for (bool done = false; !done;) {
+        // ------------------------------------------------------------ refill idle quads
+        const uint64_t idleMask = __ballot(st == 0);
+        const uint32_t nIdle = uint32_t(__popcll(idleMask & kQuadLane0));
+        uint64_t liveMask = ~idleMask;
+        // a refill pass costs a trip through the ray-setup code for the whole wave: wait until a few quads are
+        // idle (or nothing else is left to do) so that one pass serves several rays
+        if (!exhausted && (nIdle >= a.refill_min || nIdle == kRaysPerWave)) {
             if (chunkNext >= chunkEnd) {
                 uint32_t c = 0;
                 if (lane == 0)
                     c = atomicAdd(a.cursor, a.chunk);
-                c = __builtin_amdgcn_readfirstlane(c);
+                c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
                 chunkNext = c;
                 chunkEnd = min(c + a.chunk, a.n_work);
                 if (c >= a.n_work) {
@@ -254,245 +301,238 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                     chunkEnd = chunkNext;
                 }
             }
-            const uint32_t rank = __popcll(idle & ((1ull << groupShift) - 1ull));
+            // idle quads below this one (the marker bit sits in lane 3 so that a quad does not count itself)
+            const uint64_t marks = idleMask & kQuadLane3;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(marks >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(marks), 0u));
             const uint32_t w = chunkNext + rank;
-            const bool take = !active && w < chunkEnd;
-            chunkNext = min(chunkNext + nIdle, chunkEnd);
+            const bool take = st == 0 && w < chunkEnd;
+            chunkNext = uint32_t(__builtin_amdgcn_readfirstlane(int(min(chunkNext + nIdle, chunkEnd))));
+            liveMask |= __ballot(take);
             if (take) {
                 rayId = a.work_ray ? a.work_ray[w] : w;
-                bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
+                const uint32_t bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
                 tag = a.work_tag ? a.work_tag[w] : 0u;
                 const Bvh8Dev bd = a.bvhs[bvhId];
-                nodes = bd.nodes;
-                tris = bd.tris;
-                ox = a.ox[rayId];
-                oy = a.oy[rayId];
-                oz = a.oz[rayId];
-                dx = a.dx[rayId];
-                dy = a.dy[rayId];
-                dz = a.dz[rayId];
-                tnear = a.tnear[rayId];
-                tfar = a.tfar_in[rayId];
-                ix = 1.0f / dx; // wive_bvh8_impl.h:66-68: no zero guard
-                iy = 1.0f / dy;
-                iz = 1.0f / dz;
-                shift = ((dx > 0 ? 1u : 0u) | (dy > 0 ? 2u : 0u) | (dz > 0 ? 4u : 0u)) * 3u; // :384-388
+                nodePiece = bd.nodes + myPiece16;
+                triMine = bd.tris + q * 48u;
+                const float va = loadA[rayId], vb = loadB[rayId];
+                const float inv = 1.0f / vb; // wive_bvh8_impl.h:66-68: no zero guard (lane 3: unused)
                 // rays that can meet 0 * inf (or carry inf/NaN themselves) take the x86-exact slab test
                 const float big = 3.4028234663852886e38f;
-                const bool tame = fabsf(ix) <= big && fabsf(iy) <= big && fabsf(iz) <= big && ix != 0.0f && iy != 0.0f && iz != 0.0f
-                    && fabsf(ox) <= big && fabsf(oy) <= big && fabsf(oz) <= big && tnear == tnear && tfar == tfar;
-                exact = !tame || bd.needs_exact != 0u;
-                rdNearX = ix < 0.0f ? nodeRd[1] : nodeRd[0];
-                rdFarX = ix < 0.0f ? nodeRd[0] : nodeRd[1];
-                rdNearY = iy < 0.0f ? nodeRd[3] : nodeRd[2];
-                rdFarY = iy < 0.0f ? nodeRd[2] : nodeRd[3];
-                rdNearZ = iz < 0.0f ? nodeRd[5] : nodeRd[4];
-                rdFarZ = iz < 0.0f ? nodeRd[4] : nodeRd[5];
+                const bool tame = q < 3u ? (fabsf(inv) <= big && inv != 0.0f && fabsf(va) <= big) : (va == va && vb == vb);
+                exact = quadOr(tame ? 0u : 1u) | bd.needs_exact;
+                shift = quadOr(q < 3u && vb > 0.0f ? qbit : 0u) * 3u; // :384-388
+                ox = quadBcast<0>(va);
+                oy = quadBcast<1>(va);
+                oz = quadBcast<2>(va);
+                tnear = quadBcast<3>(va);
+                dx = quadBcast<0>(vb);
+                dy = quadBcast<1>(vb);
+                dz = quadBcast<2>(vb);
+                tfar = quadBcast<3>(vb);
+                ix = quadBcast<0>(inv);
+                iy = quadBcast<1>(inv);
+                iz = quadBcast<2>(inv);
+                rdNearX = ix < 0.0f ? pairOdd : pairEven;
+                rdFarX = ix < 0.0f ? pairEven : pairOdd;
+                rdNearY = (iy < 0.0f ? pairOdd : pairEven) + 1024;
+                rdFarY = (iy < 0.0f ? pairEven : pairOdd) + 1024;
+                rdNearZ = (iz < 0.0f ? pairOdd : pairEven) + 2048;
+                rdFarZ = (iz < 0.0f ? pairEven : pairOdd) + 2048;
                 hitObj = PGPU_MISS_ID;
                 hitU = hitV = 0.0f;
                 if (q == 0)
-                    stack[0] = make_uint2(bd.root, __float_as_uint(0.0f)); // :80-82
+                    ldsStoreU2(stackBase, make_uint2(bd.root, __float_as_uint(0.0f))); // :80-82
                 sp = 1;
                 hitMark = 0;
-                active = true;
+                st = 1;
             }
             if (STATS)
                 statRefill += (lane == 0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (__ballot(active) == 0) {
-            if (exhausted)
-                break;
-            continue;
-        }
-
-        // ------------------------------------------------------------ pop: the top LPR entries at once
-        // A ray that popped a leaf keeps the handle and sits out (pend) until the wave runs a leaf pass: the
+        if (liveMask == 0) {
+            done = exhausted;
+        } else {
+        // ------------------------------------------------------------ pop: the top 4 entries at once
+        // A ray that popped a leaf keeps the handle and sits out (st 2) until the wave runs a leaf pass: the
         // triangle code is long, so it runs once several rays of the wave wait for it (or nothing else is
         // left to do) rather than in every step for the one or two rays that happen to be at a leaf.
-        const bool popNow = active && !pend;
-        bool isInner = false;
         {
-            const int e = sp - 1 - int(q);
+            const bool run = st == 1;
+            const int top = sp - 1;
+            const int e = top - int(q);
+            const bool valid = run && e >= 0;
+            const bool deep = __ballot(uint32_t(sp) > W) != 0; // some stack reaches beyond the LDS window
             uint2 ent = make_uint2(0u, 0u);
-            if (popNow && e >= 0)
-                ent = stackLoad(e);
-            const bool ok = popNow && e >= 0 && (e >= hitMark || __uint_as_float(ent.y) < tfar);
-            const uint32_t gb = uint32_t(__ballot(ok) >> groupShift) & GE::kGroupMask;
-            const uint32_t first = gb != 0 ? uint32_t(__builtin_ctz(gb)) : 0u;
-            const uint32_t popped = uint32_t(__builtin_amdgcn_ds_bpermute(int((lane - q + first) << 2), int(ent.x)));
-            if (popNow) {
-                if (gb != 0) {
-                    sp = sp - 1 - int(first);
-                    handle = popped;
-                    isInner = (popped >> 29) == 2u;
-                    pend = !isInner;
-                } else {
-                    sp = max(sp - LPR, 0); // every candidate was culled
-                }
-                hitMark = min(hitMark, sp);
+            if (valid) {
+                if (!deep)
+                    ent = ldsU2(stackBase + uint32_t(e) * 8u);
+                else
+                    ent = stackLoad(uint32_t(e));
             }
+            const bool ok = valid && (e >= hitMark || __uint_as_float(ent.y) < tfar);
+            const uint32_t m = quadOr(ok ? qbit : 0u);
+            const uint32_t first = uint32_t(__builtin_ctz(m | 16u));
+            const uint32_t popped = uint32_t(__builtin_amdgcn_ds_bpermute(int(quadLane0x4 + (first << 2)), int(ent.x)));
+            const bool got = run && m != 0u;
+            sp = run ? (m != 0u ? top - int(first) : max(sp - 4, 0)) : sp; // (no survivor: all 4 candidates were culled)
+            hitMark = min(hitMark, sp);
+            handle = got ? popped : handle;
+            st = got ? ((popped >> 29) == 2u ? 3 : 2) : st;
         }
-        const uint64_t pendMask = __ballot(pend);
-        const bool leafPass = pendMask != 0 && (uint32_t(__popcll(pendMask & GE::kOneBitPerGroup)) >= a.leaf_min || __ballot(isInner) == 0);
-        const bool isLeaf = pend && leafPass;
-        const bool have = isInner || isLeaf;
+        const uint64_t pendMask = __ballot(st == 2);
+        const uint64_t innerMask = __ballot(st == 3);
+        const bool leafPass = __builtin_amdgcn_readfirstlane(
+            pendMask != 0 && (uint32_t(__popcll(pendMask & kQuadLane0)) >= a.leaf_min || innerMask == 0) ? 1 : 0) != 0;
         const uint32_t index = handle & 0x1FFFFFFFu;
-        const uint32_t count = ((handle >> 29) & 3u) + 1u; // :378-382
         if (STATS) {
             statIter += (lane == 0);
             statLeafPass += (lane == 0 && leafPass);
         }
 
-        // ------------------------------------------------------------ fetch node / leaf triangles into LDS
-        {
-            const unsigned char* base = isInner ? nodes + size_t(index) * 256u : tris + size_t(index) * 48u;
-            const uint32_t pieces = isInner ? 16u : 3u * count;
-#pragma unroll
-            for (uint32_t h = 0; h < GE::NDMA; ++h)
-                if (have && h * LPR + myPiece < pieces)
-                    ldsDma16(base + (h * LPR + myPiece) * 16u, stage + h * 1024u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ------------------------------------------------------------ fetch: node -> LDS (4 x 1 KiB LDS-DMA per wave),
+        // leaf triangles -> registers (record q of the leaf's <= 4 consecutive 48-byte records)
+        float4 p0, p1, p2; // (set and used by the triangle lanes of a leaf pass only)
+        const bool triLane = leafPass && st == 2 && q <= ((handle >> 29) & 3u); // count - 1 = low two flag bits (:378-382)
+        if (triLane) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) f4v* gf4;
+            gf4 t = (gf4)(triMine + size_t(index) * 48u);
+            const f4v r0 = t[0], r1 = t[1], r2 = t[2];
+            p0 = make_float4(r0.x, r0.y, r0.z, r0.w);
+            p1 = make_float4(r1.x, r1.y, r1.z, r1.w);
+            p2 = make_float4(r2.x, r2.y, r2.z, r2.w);
         }
-
-        // ------------------------------------------------------------ inner node: slab test of this lane's children
-        if (isInner) {
-            float tmin[CPL], tmax[CPL];
-            uint32_t child[CPL], perm[CPL];
-            float nX[CPL], fX[CPL], nY[CPL], fY[CPL], nZ[CPL], fZ[CPL];
-            const bool slow = __ballot(exact) != 0;
-#pragma unroll
-            for (uint32_t i = 0; i < CPL; ++i) {
-                child[i] = ldsU(nodeRd[6] + 4u * i);
-                perm[i] = ldsU(nodeRd[7] + 4u * i);
-            }
-            if (!slow) {
-                // No ray of this wave can produce a NaN (finite non-zero 1/d, finite origin, ordered boxes), so
-                // min(t1,t2) is the plane on the ray's near side: picked through the LDS address (rdNear/rdFar,
-                // set per ray from the sign of 1/d), and the max/min chains are plain IEEE max3/min3.
-#pragma unroll
-                for (uint32_t i = 0; i < CPL; ++i) {
-                    nX[i] = ldsF(rdNearX + 4u * i);
-                    fX[i] = ldsF(rdFarX + 4u * i);
-                    nY[i] = ldsF(rdNearY + 4u * i);
-                    fY[i] = ldsF(rdFarY + 4u * i);
-                    nZ[i] = ldsF(rdNearZ + 4u * i);
-                    fZ[i] = ldsF(rdFarZ + 4u * i);
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < CPL; ++i) {
-                    const float tnx = (nX[i] - ox) * ix, tfx = (fX[i] - ox) * ix;
-                    const float tny = (nY[i] - oy) * iy, tfy = (fY[i] - oy) * iy;
-                    const float tnz = (nZ[i] - oz) * iz, tfz = (fZ[i] - oz) * iz;
-                    tmin[i] = fmaxf(tnear, fmaxf(fmaxf(tnx, tny), tnz));
-                    tmax[i] = fminf(tfar, fminf(fminf(tfx, tfy), tfz));
-                }
-            } else {
-#pragma unroll
-                for (uint32_t i = 0; i < CPL; ++i) {
-                    const float lox = ldsF(nodeRd[0] + 4u * i), hix = ldsF(nodeRd[1] + 4u * i);
-                    const float loy = ldsF(nodeRd[2] + 4u * i), hiy = ldsF(nodeRd[3] + 4u * i);
-                    const float loz = ldsF(nodeRd[4] + 4u * i), hiz = ldsF(nodeRd[5] + 4u * i);
-                    const float tx1 = (lox - ox) * ix, tx2 = (hix - ox) * ix; // :212-217
-                    const float ty1 = (loy - oy) * iy, ty2 = (hiy - oy) * iy;
-                    const float tz1 = (loz - oz) * iz, tz2 = (hiz - oz) * iz;
-                    const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
-                    const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
-                    tmin[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin))); // :224
-                    tmax[i] = min86(tfar, min86(txMax, min86(tyMax, tzMax)));  // :225
-                }
-            }
-            // slot j (far -> near) takes the child named by the octant permutation (:229-232,235); a child that
-            // fails tmin <= tmax (:233) travels as 0xFFFFFFFF
-            uint32_t pChild[CPL];
-            float pTmin[CPL];
-            if (CPL == 1) {
-                const uint32_t src = (lane - q) + ((perm[0] >> shift) & 7u);
-                pChild[0] = uint32_t(__builtin_amdgcn_ds_bpermute(int(src << 2), int(tmin[0] <= tmax[0] ? child[0] : 0xFFFFFFFFu)));
-                pTmin[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(int(src << 2), __float_as_int(tmin[0])));
-            } else {
-#pragma unroll
-                for (uint32_t i = 0; i < CPL; ++i)
-                    order[q * CPL + i] = make_uint2(tmin[i] <= tmax[i] ? child[i] : 0xFFFFFFFFu, __float_as_uint(tmin[i]));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (uint32_t i = 0; i < CPL; ++i) {
-                    const uint2 e = order[(perm[i] >> shift) & 7u];
-                    pChild[i] = e.x;
-                    pTmin[i] = __uint_as_float(e.y);
-                }
-            }
-            // compress (:234-237): rank of every kept slot among the kept slots of this ray, slot order
-            uint32_t rank = 0, total = 0;
-            bool keep[CPL];
-#pragma unroll
-            for (uint32_t i = 0; i < CPL; ++i) {
-                keep[i] = pChild[i] != 0xFFFFFFFFu;
-                const uint32_t gb = uint32_t(__ballot(keep[i]) >> groupShift) & GE::kGroupMask;
-                rank += __popc(gb & ((1u << q) - 1u));
-                total += __popc(gb);
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < CPL; ++i) {
-                if (keep[i])
-                    stackStore(sp + int(rank), make_uint2(pChild[i], __float_as_uint(pTmin[i])));
-                rank += keep[i] ? 1u : 0u;
-            }
-            sp += int(total);
-            if (STATS)
-                statInner += (q == 0);
+        if (st == 3) {
+            const unsigned char* src = nodePiece + size_t(index) * 256u;
+            nodeDma<0>(src, stageU);
+            nodeDma<1>(src, stageU);
+            nodeDma<2>(src, stageU);
+            nodeDma<3>(src, stageU);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-        // ------------------------------------------------------------ leaf: <= 4 triangles, one per lane
-        if (isLeaf) {
+        // ------------------------------------------------------------ leaf pass: <= 4 triangles, one per lane
+        if (leafPass) {
+            const bool isLeaf = st == 2;
             TriHit th;
             th.hit = false;
             th.t = th.u = th.v = 0.0f;
-            uint32_t obj = 0;
-            if (q < count) {
-                const float4 p0 = *reinterpret_cast<const float4*>(triRd[0]);
-                const float4 p1 = *reinterpret_cast<const float4*>(triRd[1]);
-                const float4 p2 = *reinterpret_cast<const float4*>(triRd[2]);
-                obj = __float_as_uint(p0.w);
+            if (triLane) {
                 th = TRI == PGPU_TRI_WATERTIGHT_ID ? triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2)
                                                    : triMT(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2);
                 if (STATS)
                     statTri += 1;
             }
             if (STATS)
-                statLeaf += (q == 0);
+                statLeaf += (isLeaf && q == 0);
             // The reference tests the leaf's objects in order, each seeing the tfar left by the previous
             // one and accepting t <= tfar (:272-280). The survivor of that sequence is the LAST object
             // whose t equals the minimum of the valid t's.
-            float best = th.hit ? th.t : __builtin_inff();
-            best = fminf(best, __shfl_xor(best, 1));
-            best = fminf(best, __shfl_xor(best, 2));
-            const bool winner = th.hit && th.t == best;
-            const uint32_t gb = uint32_t(__ballot(winner) >> groupShift) & 0xFu;
-            if (gb != 0) {
-                const uint32_t w = 31u - __builtin_clz(gb);
-                const int srcAddr = int((lane - q + w) << 2);
-                if (ANY) {
-                    // :193-196: first hit ends the ray
-                    if (q == 0)
-                        a.any_out[rayId] = 1u;
-                    active = false;
-                    sp = 0;
-                } else {
-                    tfar = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.t)));
-                    hitU = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.u)));
-                    hitV = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.v)));
-                    hitObj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, int(obj)));
-                    hitMark = sp; // everything still on the stack predates this hit
+            const float best = quadMin(th.hit ? th.t : __builtin_inff());
+            const uint32_t winners = quadOr(th.hit && th.t == best ? qbit : 0u);
+            const int srcAddr = int(quadLane0x4 + ((31u - uint32_t(__builtin_clz(winners | 1u))) << 2)); // (no winner: unused)
+            const float wt = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.t)));
+            const float wu = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.u)));
+            const float wv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.v)));
+            const uint32_t wobj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(p0.w)));
+            if (isLeaf) {
+                st = 1;
+                if ((winners & 0xFu) != 0u) {
+                    if (ANY) {
+                        // :193-196: first hit ends the ray
+                        if (q == 0)
+                            a.any_out[rayId] = 1u;
+                        st = 0;
+                        sp = 0;
+                        exact = 0;
+                    } else {
+                        tfar = wt;
+                        hitU = wu;
+                        hitV = wv;
+                        hitObj = wobj;
+                        hitMark = sp; // everything still on the stack predates this hit
+                    }
                 }
             }
-            pend = false;
+        }
+
+        // ------------------------------------------------------------ inner node: slab test of this lane's two children
+        if (st == 3) {
+            const uint2 child = ldsU2(pairEven + 3072);
+            const uint2 perm = ldsU2(pairOdd + 3072);
+            f2 tmin, tmax;
+            if (__ballot(exact != 0u) == 0) {
+                // No ray of this wave can produce a NaN (finite non-zero 1/d, finite origin, ordered boxes), so
+                // min(t1,t2) is the plane on the ray's near side: picked through the LDS address (rdNear/rdFar,
+                // set per ray from the sign of 1/d), and the max/min chains are plain IEEE max3/min3.
+                const f2 nX = ldsF2(rdNearX), fX = ldsF2(rdFarX), nY = ldsF2(rdNearY), fY = ldsF2(rdFarY), nZ = ldsF2(rdNearZ), fZ = ldsF2(rdFarZ);
+                const f2 tnx = (nX - ox) * ix, tfx = (fX - ox) * ix;
+                const f2 tny = (nY - oy) * iy, tfy = (fY - oy) * iy;
+                const f2 tnz = (nZ - oz) * iz, tfz = (fZ - oz) * iz;
+                tmin.x = fmaxf(tnear, fmaxf(fmaxf(tnx.x, tny.x), tnz.x));
+                tmin.y = fmaxf(tnear, fmaxf(fmaxf(tnx.y, tny.y), tnz.y));
+                tmax.x = fminf(tfar, fminf(fminf(tfx.x, tfy.x), tfz.x));
+                tmax.y = fminf(tfar, fminf(fminf(tfx.y, tfy.y), tfz.y));
+            } else {
+                const f2 loX = ldsF2(pairEven), hiX = ldsF2(pairOdd), loY = ldsF2(pairEven + 1024), hiY = ldsF2(pairOdd + 1024);
+                const f2 loZ = ldsF2(pairEven + 2048), hiZ = ldsF2(pairOdd + 2048);
+                const float lo[3][2] = { { loX.x, loX.y }, { loY.x, loY.y }, { loZ.x, loZ.y } };
+                const float hi[3][2] = { { hiX.x, hiX.y }, { hiY.x, hiY.y }, { hiZ.x, hiZ.y } };
+                float tm[2], tM[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float tx1 = (lo[0][i] - ox) * ix, tx2 = (hi[0][i] - ox) * ix; // :212-217
+                    const float ty1 = (lo[1][i] - oy) * iy, ty2 = (hi[1][i] - oy) * iy;
+                    const float tz1 = (lo[2][i] - oz) * iz, tz2 = (hi[2][i] - oz) * iz;
+                    const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
+                    const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
+                    tm[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin))); // :224
+                    tM[i] = min86(tfar, min86(txMax, min86(tyMax, tzMax)));  // :225
+                }
+                tmin.x = tm[0];
+                tmin.y = tm[1];
+                tmax.x = tM[0];
+                tmax.y = tM[1];
+            }
+            // slot j (far -> near) takes the child named by the octant permutation (:229-232,235); a child that
+            // fails tmin <= tmax (:233) travels as 0xFFFFFFFF. The 8 (child, tmin) pairs of the ray go through the
+            // (already consumed) first 64 bytes of its staged node.
+            {
+                ldsStoreU4(orderBase + q * 16u, tmin.x <= tmax.x ? child.x : 0xFFFFFFFFu, __float_as_uint(tmin.x),
+                    tmin.y <= tmax.y ? child.y : 0xFFFFFFFFu, __float_as_uint(tmin.y));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint2 s0 = ldsU2(orderBase + (__builtin_amdgcn_ubfe(perm.x, shift, 3u) << 3));
+            const uint2 s1 = ldsU2(orderBase + (__builtin_amdgcn_ubfe(perm.y, shift, 3u) << 3));
+            // compress (:234-237): slots are pushed in slot order; this lane's slots are 2q and 2q+1
+            const uint32_t k0 = s0.x != 0xFFFFFFFFu ? 1u : 0u, k1 = s1.x != 0xFFFFFFFFu ? 1u : 0u;
+            const uint32_t counts = quadAdd((k0 + k1) << (q * 8u)); // byte l = kept slots of lane l
+            const uint32_t at0 = __builtin_amdgcn_sad_u8(counts & ((1u << (q * 8u)) - 1u), 0u, uint32_t(sp));
+            const uint32_t at1 = at0 + k0;
+            const int spNew = int(__builtin_amdgcn_sad_u8(counts, 0u, uint32_t(sp)));
+            if (__ballot(uint32_t(spNew) > W) == 0) {
+                if (k0)
+                    ldsStoreU2(stackBase + at0 * 8u, s0);
+                if (k1)
+                    ldsStoreU2(stackBase + at1 * 8u, s1);
+            } else {
+                if (k0)
+                    stackStore(at0, s0);
+                if (k1)
+                    stackStore(at1, s1);
+            }
+            sp = spNew;
+            st = 1;
+            if (STATS)
+                statInner += (q == 0);
         }
 
         // ------------------------------------------------------------ retire rays whose stack ran dry
-        if (active && sp == 0 && !pend) {
+        if (st == 1 && sp == 0) {
             if (q == 0) {
                 if (ANY) {
                     if (a.init_miss)
@@ -512,12 +552,12 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                     }
                 }
             }
-            active = false;
+            st = 0;
+            exact = 0;
         }
-        if (!active)
-            exact = false;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        } // live rays
     }
 
     if (STATS && a.stats) {
@@ -534,20 +574,17 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
 
 } // namespace
 
-size_t bvh8TraceLdsBytes(uint32_t stackEntries, int lanesPerRay)
+size_t bvh8TraceLdsBytes(uint32_t stackEntries)
 {
-    const uint32_t groups = 64u / uint32_t(lanesPerRay);
-    const uint32_t order = lanesPerRay == 8 ? 0u : groups * 64u;
-    return kWavesPerBlock * (groups * 256u + order) + kWavesPerBlock * groups * stackStrideBytes(stackEntries);
+    return kWavesPerBlock * kStagePerWave + kWavesPerBlock * kRaysPerWave * stackStrideBytes(stackEntries);
 }
 
-template <int LPR>
-static hipError_t launchLpr(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
+hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
 {
     const dim3 grid(blocks), block(256);
-    const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries, LPR);
+    const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries);
 #define PANDORA_LAUNCH(ANYV, TRIV, STATV) \
-    hipLaunchKernelGGL((bvh8TraceKernel<LPR, ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args)
+    hipLaunchKernelGGL((bvh8TraceKernel<ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args)
     if (kind == PGPU_ANY_ID) {
         if (triMode == PGPU_TRI_WATERTIGHT_ID) {
             if (stats) PANDORA_LAUNCH(true, 1, true); else PANDORA_LAUNCH(true, 1, false);
@@ -563,11 +600,6 @@ static hipError_t launchLpr(const Bvh8TraceArgs& args, int kind, int triMode, bo
     }
 #undef PANDORA_LAUNCH
     return hipGetLastError();
-}
-
-hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, int lanesPerRay, uint32_t blocks, hipStream_t stream)
-{
-    return lanesPerRay == 4 ? launchLpr<4>(args, kind, triMode, stats, blocks, stream) : launchLpr<8>(args, kind, triMode, stats, blocks, stream);
 }
 
 } // namespace pandora_hip

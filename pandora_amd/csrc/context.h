@@ -25,7 +25,6 @@ struct pgpu_ctx {
     bool stats = false;
     int blocksPerCU = 0; // 0 = as many as LDS / registers allow
     uint32_t chunk = 64;
-    int lanesPerRay = 4;     // 8 or 4, see bvh8_kernels.hip
     uint32_t refillMin = 3;
     uint32_t leafMin = 0; // 0: automatic
     int stackWindow = 0;     // LDS stack entries per ray, 0 = automatic

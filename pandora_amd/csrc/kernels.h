@@ -96,29 +96,29 @@ hipError_t launchBinByLeaf(const uint32_t* parkedRay, const uint32_t* parkedLeaf
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);
 
-size_t bvh8TraceLdsBytes(uint32_t stackEntries, int lanesPerRay);
+size_t bvh8TraceLdsBytes(uint32_t stackEntries);
 inline uint32_t stackEntriesForDepth(uint32_t depth)
 {
     const uint32_t need = 7u * depth + 8u; // each inner visit pops 1 and pushes <= 8 (wive_bvh8_impl.h:97-102)
     return need < 16u ? 16u : ((need + 7u) & ~7u);
 }
 // LDS window of the per-ray stack: the whole worst case when it is small, otherwise a window sized so that
-// 6 (8 lanes per ray) or 5 (4 lanes per ray) blocks fit a CU; deeper entries spill to global memory.
-inline uint32_t stackWindow(uint32_t need, int lanesPerRay, int requested)
+// 5 blocks fit a CU; deeper entries spill to global memory.
+inline uint32_t stackWindow(uint32_t need, int requested)
 {
-    const uint32_t cap = requested > 0 ? uint32_t(requested) : (lanesPerRay == 4 ? 12u : 64u);
+    const uint32_t cap = requested > 0 ? uint32_t(requested) : 20u;
     return need < cap ? need : cap;
 }
-// blocks of 256 threads per CU: requested, or (0) as many as LDS (160 KiB) and registers (<= 80 VGPR -> 6) allow
-inline uint32_t blocksPerCU(int requested, uint32_t stackEntries, int lanesPerRay)
+// blocks of 256 threads per CU: requested, or (0) as many as LDS (160 KiB) and registers allow
+inline uint32_t blocksPerCU(int requested, uint32_t stackEntries)
 {
-    const uint32_t byLds = uint32_t((160u * 1024u) / bvh8TraceLdsBytes(stackEntries, lanesPerRay));
-    const uint32_t byRegs = lanesPerRay == 4 ? 5u : 6u; // 87 / 79 VGPRs
+    const uint32_t byLds = uint32_t((160u * 1024u) / bvh8TraceLdsBytes(stackEntries));
+    const uint32_t byRegs = 5u; // <= 96 VGPRs
     const uint32_t cap = byLds < byRegs ? byLds : byRegs;
     if (requested <= 0)
         return cap < 1u ? 1u : cap;
     return uint32_t(requested) < cap ? uint32_t(requested) : cap;
 }
-hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, int lanesPerRay, uint32_t blocks, hipStream_t stream);
+hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream);
 
 } // namespace pandora_hip

@@ -343,7 +343,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         rc = planBvh8Launch(c, deepest, parked, ba, &blocks);
         if (rc != PGPU_OK)
             return rc;
-        HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, c->lanesPerRay, blocks, stream));
+        HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
         active = dWorkRay;
         nActive = parked;
     }

@@ -39,12 +39,11 @@ def _ray_sets(mesh, orc, res=96):
 # (lanes per ray, refill threshold, LDS stack window): window 0 = automatic, a small window forces most of
 # the stack through the global spill buffer
 # leaf_min: how many rays of a wave wait at a leaf before the triangle code runs (1 = every step)
-@pytest.mark.parametrize("lanes_per_ray,refill_min,window,leaf_min",
-                         [(8, 1, 0, 0), (4, 2, 0, 0), (4, 5, 0, 1), (4, 2, 4, 16), (8, 2, 4, 8), (4, 2, 1, 7)])
+@pytest.mark.parametrize("refill_min,window,leaf_min", [(3, 0, 0), (1, 0, 1), (5, 0, 3), (2, 4, 16), (2, 1, 7), (16, 8, 0)])
 @pytest.mark.parametrize("tri_mode", [pa.capi.TRI_MT, pa.capi.TRI_WATERTIGHT])
-def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode, lanes_per_ray, refill_min, window, leaf_min):
+def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode, refill_min, window, leaf_min):
     mesh, hb, bvh, orc = small
-    gpu_ctx.set_kernel_variant(lanes_per_ray, refill_min, window, leaf_min)
+    gpu_ctx.set_kernel_variant(refill_min, window, leaf_min)
     for name, rays in _ray_sets(mesh, orc).items():
         got = gpu_ctx.trace_bvh8(bvh, rays, tri_mode=tri_mode)
         want = orc.trace(rays, tri_mode=tri_mode)
@@ -52,4 +51,4 @@ def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode, lanes_per_ray, r
         got_any = gpu_ctx.trace_bvh8(bvh, rays, kind=pa.capi.ANY, tri_mode=tri_mode)["hit"]
         want_any = orc.trace(rays, any_hit=True, tri_mode=tri_mode)["hit"]
         assert np.array_equal(got_any, want_any), f"{name}: any-hit differs"
-    gpu_ctx.set_kernel_variant(4, 2, 0, 0)
+    gpu_ctx.set_kernel_variant(3, 0, 0)

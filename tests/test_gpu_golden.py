@@ -18,8 +18,8 @@ def test_bvh8_golden(gpu_ctx):
     host = pa.accel.HostBvh8(np.ascontiguousarray(z["nodes"]), np.ascontiguousarray(z["leaf_idx"]), int(z["root"]), 0, np.ascontiguousarray(z["prim_ids"]))
     bvh = gpu_ctx.upload_bvh8(host, gpu_ctx.upload_mesh(z["pos"], z["idx"]))
     rays = np.ascontiguousarray(z["rays"])
-    for tri, lpr in ((0, 4), (1, 4), (0, 8), (1, 8)):
-        gpu_ctx.set_kernel_variant(lpr, 2)
+    for tri, window in ((0, 0), (1, 0), (0, 3), (1, 3)):
+        gpu_ctx.set_kernel_variant(3, window, 0)
         got = gpu_ctx.trace_bvh8(bvh, rays, tri_mode=tri)
         for k in ("t", "obj", "u", "v"):
             bad = np.nonzero(_bits(got[k]) != _bits(z[f"tri{tri}_{k}"]))[0]

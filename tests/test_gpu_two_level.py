@@ -37,10 +37,10 @@ def _ray_sets(mesh):
     return {"primary": prim, "diffuse": diff, "shadow": shad, "random": rnd, "far": far}
 
 
-@pytest.mark.parametrize("lanes_per_ray", [4, 8])
-def test_two_level_matches_oracle(two_level, lanes_per_ray):
+@pytest.mark.parametrize("window,leaf_min", [(0, 0), (2, 9)])
+def test_two_level_matches_oracle(two_level, window, leaf_min):
     ctx, mesh, tl, orc = two_level
-    ctx.set_kernel_variant(lanes_per_ray, 2)
+    ctx.set_kernel_variant(3, window, leaf_min)
     for name, rays in _ray_sets(mesh).items():
         got, cnt = ctx.trace(rays)
         want = orc.trace(rays, lanes=3)

@@ -22,9 +22,10 @@ ddiff = torch.from_numpy(diff).cuda()
 n = diff.shape[1]
 o2 = ctx.trace_bvh8(bvh, ddiff); ctx.sync()
 print("diffuse (stats on): %.3f ms, %.1f Mrays/s" % (ctx.last_kernel_ms(), n / ctx.last_kernel_ms() / 1e3), ctx.counters(), flush=True)
-for lpr, rmin, bpc, chunk, win, lmin in ((8, 2, 0, 64, 0, 0), (8, 2, 0, 64, 0, 1), (8, 2, 0, 64, 0, 3), (4, 2, 0, 64, 12, 1), (4, 2, 0, 64, 12, 2), (4, 2, 0, 64, 12, 3), (4, 2, 0, 64, 12, 4),
-                                      (4, 2, 0, 64, 12, 6), (4, 2, 0, 64, 12, 8), (4, 2, 0, 64, 12, 12), (4, 3, 0, 64, 12, 4), (4, 4, 0, 64, 12, 4), (4, 2, 0, 64, 0, 4), (4, 2, 0, 64, 10, 4), (4, 2, 0, 64, 8, 4)):
-    ctx.set_kernel_variant(lpr, rmin, win, lmin)
+lpr = 4
+for rmin, bpc, chunk, win, lmin in ((3, 0, 64, 0, 0), (2, 0, 64, 0, 0), (4, 0, 64, 0, 0), (6, 0, 64, 0, 0), (3, 0, 64, 0, 2), (3, 0, 64, 0, 3), (3, 0, 64, 0, 5), (3, 0, 64, 0, 6),
+                                 (3, 0, 64, 12, 0), (3, 0, 64, 16, 0), (3, 0, 64, 24, 0), (3, 0, 64, 64, 0), (3, 4, 64, 0, 0), (3, 0, 32, 0, 0), (3, 0, 128, 0, 0)):
+    ctx.set_kernel_variant(rmin, win, lmin)
     ctx.set_tuning(bpc, chunk)
     ctx.set_stats(True)
     ctx.trace_bvh8(bvh, ddiff, out=o2); ctx.sync()
@@ -37,7 +38,7 @@ for lpr, rmin, bpc, chunk, win, lmin in ((8, 2, 0, 64, 0, 0), (8, 2, 0, 64, 0, 1
     print("diffuse lpr=%d refill_min=%d bpc=%d chunk=%d win=%d leaf_min=%d: best %.3f ms median %.3f ms -> %.1f Mrays/s | steps %.1fM leaf passes %.1fM refills %.1fM util %.2f" % (
         lpr, rmin, bpc, chunk, win, lmin, min(ms), sorted(ms)[2], n / min(ms) / 1e3, cn["wave_steps"] / 1e6, cn["leaf_passes"] / 1e6, cn["refill_passes"] / 1e6,
         (cn["inner_visits"] + cn["leaf_pops"]) / max(1, cn["wave_steps"] * g)), flush=True)
-ctx.set_kernel_variant(4, 2, 0, 0)
+ctx.set_kernel_variant(3, 0, 0)
 ctx.set_tuning(0, 64)
 ms = []
 for it in range(5):
