@@ -195,6 +195,8 @@ __device__ __forceinline__ void nodeDma(const unsigned char* gsrc, __attribute__
 }
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+// the other array of a min/max pair (they sit 32 bytes apart and the staging area is 64-byte aligned)
+__device__ __forceinline__ const lds_u8* ldsFlip32(const lds_u8* p) { return (const lds_u8*)(uintptr_t)(uint32_t(uintptr_t(p)) ^ 32u); }
 __device__ __forceinline__ f2 ldsF2(const lds_u8* p) { return *reinterpret_cast<const __attribute__((address_space(3))) f2*>(p); }
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -261,22 +263,23 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
         return make_uint2(uint32_t(v), uint32_t(v >> 32));
     };
 
-    // refill: lane q of a quad loads component q of the origin and of the direction (lane 3: tnear, tfar)
-    const float* const loadA = q == 0 ? a.ox : (q == 1 ? a.oy : (q == 2 ? a.oz : a.tnear));
-    const float* const loadB = q == 0 ? a.dx : (q == 1 ? a.dy : (q == 2 ? a.dz : a.tfar_in));
 
     // per-ray state, replicated over the 4 lanes of the quad
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
     float hitU = 0, hitV = 0;
-    uint32_t hitObj = PGPU_MISS_ID, shift = 0, rayId = 0, tag = 0, handle = 0;
+    uint32_t hitObj = PGPU_MISS_ID, rayId = 0, tag = 0, handle = 0;
+    // bits 4:0 = the octant's bit offset into a permutation word (:384-388); bit 8 = this ray needs the x86-exact
+    // slab test (v_bfe_u32 reads only the low 5 bits of its offset operand)
+    uint32_t shift = 0;
     const unsigned char* nodePiece = nullptr; // nodes + this lane's piece offset
     const unsigned char* triMine = nullptr;   // tris + q * 48: triangle q of leaf slot 0
     int sp = 0, hitMark = 0;
     // 0 idle, 1 traversing, 2 waiting at a popped leaf (handle) for the wave's next leaf pass, 3 (inside one step
     // only) popped an inner node (handle)
     int st = 0;
-    uint32_t exact = 0; // 1: this ray needs the x86-exact slab test
-    const lds_u8 *rdNearX = pairEven, *rdFarX = pairOdd, *rdNearY = pairEven, *rdFarY = pairOdd, *rdNearZ = pairEven, *rdFarZ = pairOdd;
+    // LDS offsets of the near-side plane pair per axis (min array if 1/d >= 0 else max array); the far side is 32 bytes
+    // away in the direction given by bit 5
+    const lds_u8 *rdNearX = pairEven, *rdNearY = pairEven, *rdNearZ = pairEven;
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     bool exhausted = false;
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
@@ -315,13 +318,16 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                 const Bvh8Dev bd = a.bvhs[bvhId];
                 nodePiece = bd.nodes + myPiece16;
                 triMine = bd.tris + q * 48u;
+                // lane q of the quad loads component q of the origin and of the direction (lane 3: tnear, tfar)
+                const float* const loadA = q == 0 ? a.ox : (q == 1 ? a.oy : (q == 2 ? a.oz : a.tnear));
+                const float* const loadB = q == 0 ? a.dx : (q == 1 ? a.dy : (q == 2 ? a.dz : a.tfar_in));
                 const float va = loadA[rayId], vb = loadB[rayId];
                 const float inv = 1.0f / vb; // wive_bvh8_impl.h:66-68: no zero guard (lane 3: unused)
                 // rays that can meet 0 * inf (or carry inf/NaN themselves) take the x86-exact slab test
                 const float big = 3.4028234663852886e38f;
                 const bool tame = q < 3u ? (fabsf(inv) <= big && inv != 0.0f && fabsf(va) <= big) : (va == va && vb == vb);
-                exact = quadOr(tame ? 0u : 1u) | bd.needs_exact;
                 shift = quadOr(q < 3u && vb > 0.0f ? qbit : 0u) * 3u; // :384-388
+                shift |= (quadOr(tame ? 0u : 1u) | (bd.needs_exact != 0u ? 1u : 0u)) << 8;
                 ox = quadBcast<0>(va);
                 oy = quadBcast<1>(va);
                 oz = quadBcast<2>(va);
@@ -334,11 +340,8 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                 iy = quadBcast<1>(inv);
                 iz = quadBcast<2>(inv);
                 rdNearX = ix < 0.0f ? pairOdd : pairEven;
-                rdFarX = ix < 0.0f ? pairEven : pairOdd;
                 rdNearY = (iy < 0.0f ? pairOdd : pairEven) + 1024;
-                rdFarY = (iy < 0.0f ? pairEven : pairOdd) + 1024;
                 rdNearZ = (iz < 0.0f ? pairOdd : pairEven) + 2048;
-                rdFarZ = (iz < 0.0f ? pairEven : pairOdd) + 2048;
                 hitObj = PGPU_MISS_ID;
                 hitU = hitV = 0.0f;
                 if (q == 0)
@@ -384,8 +387,8 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
         }
         const uint64_t pendMask = __ballot(st == 2);
         const uint64_t innerMask = __ballot(st == 3);
-        const bool leafPass = __builtin_amdgcn_readfirstlane(
-            pendMask != 0 && (uint32_t(__popcll(pendMask & kQuadLane0)) >= a.leaf_min || innerMask == 0) ? 1 : 0) != 0;
+        const uint32_t leafPassU = uint32_t(pendMask != 0) & (uint32_t(uint32_t(__popcll(pendMask & kQuadLane0)) >= a.leaf_min) | uint32_t(innerMask == 0));
+        const bool leafPass = leafPassU != 0u;
         const uint32_t index = handle & 0x1FFFFFFFu;
         if (STATS) {
             statIter += (lane == 0);
@@ -394,17 +397,6 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
 
         // ------------------------------------------------------------ fetch: node -> LDS (4 x 1 KiB LDS-DMA per wave),
         // leaf triangles -> registers (record q of the leaf's <= 4 consecutive 48-byte records)
-        float4 p0, p1, p2; // (set and used by the triangle lanes of a leaf pass only)
-        const bool triLane = leafPass && st == 2 && q <= ((handle >> 29) & 3u); // count - 1 = low two flag bits (:378-382)
-        if (triLane) {
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            typedef const __attribute__((address_space(1))) f4v* gf4;
-            gf4 t = (gf4)(triMine + size_t(index) * 48u);
-            const f4v r0 = t[0], r1 = t[1], r2 = t[2];
-            p0 = make_float4(r0.x, r0.y, r0.z, r0.w);
-            p1 = make_float4(r1.x, r1.y, r1.z, r1.w);
-            p2 = make_float4(r2.x, r2.y, r2.z, r2.w);
-        }
         if (st == 3) {
             const unsigned char* src = nodePiece + size_t(index) * 256u;
             nodeDma<0>(src, stageU);
@@ -412,15 +404,22 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             nodeDma<2>(src, stageU);
             nodeDma<3>(src, stageU);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ------------------------------------------------------------ leaf pass: <= 4 triangles, one per lane
         if (leafPass) {
             const bool isLeaf = st == 2;
+            const bool triLane = isLeaf && q <= ((handle >> 29) & 3u); // count - 1 = low two flag bits (:378-382)
             TriHit th;
             th.hit = false;
             th.t = th.u = th.v = 0.0f;
+            uint32_t obj = 0;
             if (triLane) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(1))) f4v* gf4;
+                gf4 t = (gf4)(triMine + size_t(index) * 48u);
+                const f4v r0 = t[0], r1 = t[1], r2 = t[2];
+                const float4 p0 = make_float4(r0.x, r0.y, r0.z, r0.w), p1 = make_float4(r1.x, r1.y, r1.z, r1.w), p2 = make_float4(r2.x, r2.y, r2.z, r2.w);
+                obj = __float_as_uint(r0.w);
                 th = TRI == PGPU_TRI_WATERTIGHT_ID ? triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2)
                                                    : triMT(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2);
                 if (STATS)
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             const float wt = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.t)));
             const float wu = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.u)));
             const float wv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.v)));
-            const uint32_t wobj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(p0.w)));
+            const uint32_t wobj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, int(obj)));
             if (isLeaf) {
                 st = 1;
                 if ((winners & 0xFu) != 0u) {
@@ -447,7 +446,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                             a.any_out[rayId] = 1u;
                         st = 0;
                         sp = 0;
-                        exact = 0;
+                        shift = 0;
                     } else {
                         tfar = wt;
                         hitU = wu;
@@ -459,16 +458,19 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
             }
         }
 
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
         // ------------------------------------------------------------ inner node: slab test of this lane's two children
         if (st == 3) {
             const uint2 child = ldsU2(pairEven + 3072);
             const uint2 perm = ldsU2(pairOdd + 3072);
             f2 tmin, tmax;
-            if (__ballot(exact != 0u) == 0) {
+            if (__ballot(shift >= 256u) == 0) {
                 // No ray of this wave can produce a NaN (finite non-zero 1/d, finite origin, ordered boxes), so
                 // min(t1,t2) is the plane on the ray's near side: picked through the LDS address (rdNear/rdFar,
                 // set per ray from the sign of 1/d), and the max/min chains are plain IEEE max3/min3.
-                const f2 nX = ldsF2(rdNearX), fX = ldsF2(rdFarX), nY = ldsF2(rdNearY), fY = ldsF2(rdFarY), nZ = ldsF2(rdNearZ), fZ = ldsF2(rdFarZ);
+                const f2 nX = ldsF2(rdNearX), fX = ldsF2(ldsFlip32(rdNearX)), nY = ldsF2(rdNearY), fY = ldsF2(ldsFlip32(rdNearY));
+                const f2 nZ = ldsF2(rdNearZ), fZ = ldsF2(ldsFlip32(rdNearZ));
                 const f2 tnx = (nX - ox) * ix, tfx = (fX - ox) * ix;
                 const f2 tny = (nY - oy) * iy, tfy = (fY - oy) * iy;
                 const f2 tnz = (nZ - oz) * iz, tfz = (fZ - oz) * iz;
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
                 }
             }
             st = 0;
-            exact = 0;
+            shift = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
