@@ -32,12 +32,10 @@ namespace {
 
 constexpr uint32_t kWavesPerBlock = 4;
 // Per-ray stack: the reference reserves 96 entries (wive_bvh8_impl.h:74-75); a tree with d nested inner
-// nodes never holds more than 7 d + 8, so the launch sizes the LDS stack from the deepest uploaded tree
-// (more blocks per CU for shallow trees). +64 B per ray: odd ray groups start 16 banks later.
-__host__ __device__ constexpr uint32_t stackStrideBytes(uint32_t entries)
-{
-    return (entries * 8u + 64u) % 128u == 0u ? entries * 8u + 32u : entries * 8u + 64u;
-}
+// nodes never holds more than 7 d + 8, so the launch sizes the LDS window from the deepest uploaded tree and
+// from what lets 6 blocks share a CU. The stride is an odd number of 8-byte entries, which spreads the 16
+// stacks of a wave over the LDS banks.
+__host__ __device__ constexpr uint32_t stackStrideBytes(uint32_t entries) { return (entries * 8u) | 8u; }
 
 __device__ __forceinline__ float min86(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float max86(float a, float b) { return a > b ? a : b; }
