@@ -144,6 +144,7 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a,
     const uint32_t window = stackWindow(need, c->stackWindow);
     a.stack_entries = window;
     a.refill_min = c->refillMin;
+    a.range_size = uint32_t((((n_work + 7) / 8 + a.chunk - 1) / a.chunk) * a.chunk);
     a.leaf_min = c->leafMin ? c->leafMin : 4u;
     a.spill_entries = need > window ? need - window : 0u;
     a.spill = nullptr;

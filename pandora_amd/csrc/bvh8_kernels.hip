@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
     // away in the direction given by bit 5
     const lds_u8 *rdNearX = pairEven, *rdNearY = pairEven, *rdNearZ = pairEven;
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
+    uint32_t range = blockIdx.x & 7u;     // blocks are dealt round-robin over the 8 XCDs
     bool exhausted = false;
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
 
@@ -290,16 +291,22 @@ __global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
         // a refill pass costs a trip through the ray-setup code for the whole wave: wait until a few quads are
         // idle (or nothing else is left to do) so that one pass serves several rays
         if (!exhausted && (nIdle >= a.refill_min || nIdle == kRaysPerWave)) {
-            if (chunkNext >= chunkEnd) {
+            // The work list is cut into 8 contiguous ranges, one per group of blocks that share an XCD (and its
+            // L2): neighbouring rays -- and, in the two-level loop, the rays of one leaf -- stay on one XCD. A wave
+            // whose home range has run dry helps with the next one.
+            for (uint32_t tried = 0; chunkNext >= chunkEnd && !exhausted;) {
                 uint32_t c = 0;
                 if (lane == 0)
-                    c = atomicAdd(a.cursor, a.chunk);
+                    c = atomicAdd(a.cursor + range * 8u, a.chunk);
                 c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
-                chunkNext = c;
-                chunkEnd = min(c + a.chunk, a.n_work);
-                if (c >= a.n_work) {
+                const uint32_t lo = range * a.range_size, hi = min(lo + a.range_size, a.n_work);
+                if (lo < hi && c < hi - lo) {
+                    chunkNext = lo + c;
+                    chunkEnd = min(chunkNext + a.chunk, hi);
+                } else if (++tried == 8u) {
                     exhausted = true;
-                    chunkEnd = chunkNext;
+                } else {
+                    range = (range + 1u) & 7u;
                 }
             }
             // idle quads below this one (the marker bit sits in lane 3 so that a quad does not count itself)

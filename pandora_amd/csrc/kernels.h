@@ -41,7 +41,8 @@ struct Bvh8TraceArgs {
     uint32_t* leaf_out;
     float *u_out, *v_out;
     uint32_t* any_out;
-    uint32_t* cursor; // zeroed before launch
+    uint32_t* cursor; // 8 work cursors (one per XCD group of blocks), 32 bytes apart, zeroed before launch
+    uint32_t range_size; // work items per cursor
     uint32_t chunk;
     uint32_t init_miss; // 1: write miss records too (single level); 0: only touch rays that hit
     uint32_t stack_entries; // stack entries per ray kept in LDS (the window)

@@ -337,7 +337,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), stream));
         HIP_TRY(c, launchBinByLeaf(dParkedRay, dParkedLeaf, dParkedCount, dLeafStart, dLeafFill, c->top.leaves, dWorkRay, dWorkBvh, dWorkLeaf,
                        std::max(1u, std::min(uint32_t(c->numCUs) * 4u, (parked + 255u) / 256u)), stream));
-        HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 4, stream));
+        HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
         ba.n_work = parked;
         uint32_t blocks = 1;
         rc = planBvh8Launch(c, deepest, parked, ba, &blocks);

@@ -152,6 +152,33 @@ __device__ __forceinline__ uint32_t hminIndex4(const float v[4])
     return 3;
 }
 
+// Many rays of a wave usually want the same counter (coherent rays park at the same batching point), and
+// same-address atomics from single lanes serialise in L2. Lanes with equal keys therefore elect a leader that adds
+// the group's size once; every lane learns its leader, its rank inside the group and the group size.
+struct KeyGroup {
+    uint32_t leader, rank, size;
+};
+__device__ __forceinline__ KeyGroup groupByKey(uint32_t key, bool active)
+{
+    KeyGroup kg;
+    kg.leader = threadIdx.x & 63u;
+    kg.rank = 0;
+    kg.size = 1;
+    uint64_t todo = __ballot(active);
+    while (todo != 0) {
+        const int l = __builtin_ctzll(todo);
+        const uint32_t k = uint32_t(__builtin_amdgcn_readlane(int(key), l));
+        const uint64_t same = __ballot(active && key == k);
+        if (active && key == k) {
+            kg.leader = uint32_t(l);
+            kg.rank = __builtin_amdgcn_mbcnt_hi(uint32_t(same >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(same), 0u));
+            kg.size = uint32_t(__popcll(same));
+        }
+        todo &= ~same;
+    }
+    return kg;
+}
+
 template <bool ANY, bool NODES_IN_LDS>
 __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
 {
@@ -168,10 +195,15 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
     const unsigned char* nodeBase = NODES_IN_LDS ? ldsNodes : a.top.nodes;
     uint32_t nTests = 0, nCulled = 0;
 
-    for (uint32_t w = blockIdx.x * kTopBlock + threadIdx.x; w < a.n_active; w += gridDim.x * kTopBlock) {
-        const uint32_t ray = a.active ? a.active[w] : w;
-        if (ANY && a.any_out[ray] != 0u)
-            continue; // shadow ray already occluded in its last leaf (offline_batching...h:246-247)
+    // (whole waves enter every trip: the parking step below uses wave-wide ballots)
+    for (uint32_t w0 = blockIdx.x * kTopBlock; w0 < a.n_active; w0 += gridDim.x * kTopBlock) {
+        const uint32_t w = w0 + threadIdx.x;
+        const bool live = w < a.n_active;
+        const uint32_t ray = live ? (a.active ? a.active[w] : w) : 0u;
+        bool parked = false;
+        uint32_t leafId = 0;
+        // a shadow ray already occluded in its last leaf is done (offline_batching...h:246-247)
+        if (live && !(ANY && a.any_out[ray] != 0u)) {
         const float ox = a.ox[ray], oy = a.oy[ray], oz = a.oz[ray];
         const float dx = a.dx[ray], dy = a.dy[ray], dz = a.dz[ray];
         const float tnear = a.tnear[ray];
@@ -179,8 +211,6 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // :241
         uint32_t node = a.node[ray];
         uint64_t stack = a.stack[ray];
-        bool parked = false;
-        uint32_t leafId = 0;
         for (;;) {
             const float* nf = reinterpret_cast<const float*>(nodeBase + size_t(node) * kTopNodeBytes);
             const uint32_t* nu = reinterpret_cast<const uint32_t*>(nf);
@@ -251,12 +281,26 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
         if (parked) {
             a.node[ray] = node;
             a.stack[ray] = stack;
-            const uint32_t slot = atomicAdd(a.parked_count, 1u);
-            a.parked_ray[slot] = ray;
-            a.parked_leaf[slot] = leafId;
-            atomicAdd(&a.leaf_count[leafId], 1u);
             if (a.visits)
                 a.visits[ray] += 1u; // Ray::numTopLevelIntersections (:283)
+        }
+        }
+        // park: one slot per ray in the round's list, one count per batching point
+        const uint64_t parkedMask = __ballot(parked);
+        if (parkedMask != 0) {
+            const uint32_t lane = threadIdx.x & 63u;
+            uint32_t base = 0;
+            if (lane == uint32_t(__builtin_ctzll(parkedMask)))
+                base = atomicAdd(a.parked_count, uint32_t(__popcll(parkedMask)));
+            base = uint32_t(__builtin_amdgcn_readlane(int(base), __builtin_ctzll(parkedMask)));
+            const KeyGroup kg = groupByKey(leafId, parked);
+            if (parked) {
+                const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(uint32_t(parkedMask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(parkedMask), 0u));
+                a.parked_ray[slot] = ray;
+                a.parked_leaf[slot] = leafId;
+                if (kg.leader == lane)
+                    atomicAdd(&a.leaf_count[leafId], kg.size);
+            }
         }
     }
     if (nTests)
@@ -297,12 +341,22 @@ __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restric
     const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf)
 {
     const uint32_t n = *parkedCount;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t leaf = parkedLeaf[i];
-        const uint32_t at = leafStart[leaf] + atomicAdd(&leafFill[leaf], 1u);
-        workRay[at] = parkedRay[i];
-        workBvh[at] = leaves[leaf].bvh;
-        workLeaf[at] = leaf;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t leaf = live ? parkedLeaf[i] : 0u;
+        const KeyGroup kg = groupByKey(leaf, live);
+        uint32_t base = 0;
+        if (live && kg.leader == lane)
+            base = atomicAdd(&leafFill[leaf], kg.size);
+        base = uint32_t(__builtin_amdgcn_ds_bpermute(int(kg.leader << 2), int(base)));
+        if (live) {
+            const uint32_t at = leafStart[leaf] + base + kg.rank;
+            workRay[at] = parkedRay[i];
+            workBvh[at] = leaves[leaf].bvh;
+            workLeaf[at] = leaf;
+        }
     }
 }
 
