@@ -70,6 +70,8 @@ struct TopDev {
     const uint32_t* dagWords;
     const SvdagDev* dags;
     uint32_t root, n_nodes, n_leaves, n_dags;
+    uint32_t dag_levels; // height of the tallest SVDAG = entries of the cast's saved-parent stack
+    uint32_t pad;
 };
 
 struct TopTraceArgs {
@@ -82,17 +84,16 @@ struct TopTraceArgs {
     uint64_t* stack;         // PauseableBVHInsertHandle.second
     uint32_t* visits;        // may be nullptr
     uint32_t* any_out;       // any-hit: 1 once occluded
-    uint32_t* parked_count;
-    uint32_t* parked_ray;
-    uint32_t* parked_leaf;
+    uint32_t* parked_leaf;   // per work item of this round: batching point it parked at, or PGPU_MISS_ID
     uint32_t* leaf_count;
     unsigned long long* counters; // [0] svdag tests, [1] svdag culled
 };
 
 bool topNodesFitLds(uint32_t nNodes);
 hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream);
-hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, hipStream_t stream);
-hipError_t launchBinByLeaf(const uint32_t* parkedRay, const uint32_t* parkedLeaf, const uint32_t* parkedCount, const uint32_t* leafStart,
+size_t topTraverseLdsBytes(const TopDev& top);
+hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream);
+hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream);
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);

@@ -69,26 +69,43 @@ int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const
     for (size_t d = 0; d < n_dags; ++d)
         if (dags[d].root >= n_words)
             return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: root offset outside the node array");
-    std::vector<uint32_t> todo;
-    std::vector<uint8_t> seen(n_words, 0);
-    for (size_t d = 0; d < n_dags; ++d)
-        todo.push_back(dags[d].root);
-    while (!todo.empty()) {
-        const uint32_t at = todo.back();
-        todo.pop_back();
-        if (seen[at])
-            continue;
-        seen[at] = 1;
-        const uint32_t desc = words[at], inner = ((desc >> 8) & 0xFFu) & ~(desc & 0xFFu);
-        const uint32_t nKids = uint32_t(__builtin_popcount(inner));
-        if (size_t(at) + nKids >= n_words + (nKids ? 0 : 1))
-            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: child table runs past the node array");
-        for (uint32_t k = 0; k < nKids; ++k) {
-            const uint32_t kid = words[at + 1 + k];
-            if (kid >= n_words)
-                return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: child offset outside the node array");
-            todo.push_back(kid);
+    // Walk every node reachable from the roots once: offsets must stay inside the array, the graph must be
+    // acyclic, and the height of the tallest DAG sizes the cast's saved-parent stack in LDS.
+    std::vector<uint8_t> state(n_words, 0), height(n_words, 0); // state: 0 new, 1 on the walk's path, 2 done
+    std::vector<std::pair<uint32_t, uint32_t>> path;            // (node, next child to look at)
+    uint32_t levels = 1;
+    for (size_t d = 0; d < n_dags; ++d) {
+        if (state[dags[d].root] == 0)
+            path.emplace_back(dags[d].root, 0u);
+        while (!path.empty()) {
+            const uint32_t at = path.back().first;
+            const uint32_t desc = words[at], inner = ((desc >> 8) & 0xFFu) & ~(desc & 0xFFu);
+            const uint32_t nKids = uint32_t(__builtin_popcount(inner));
+            if (path.back().second == 0) {
+                state[at] = 1;
+                if (nKids && size_t(at) + nKids >= n_words)
+                    return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: child table runs past the node array");
+            }
+            if (path.back().second < nKids) {
+                const uint32_t kid = words[at + 1 + path.back().second++];
+                if (kid >= n_words)
+                    return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: child offset outside the node array");
+                if (state[kid] == 1)
+                    return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: the node graph has a cycle");
+                if (state[kid] == 0)
+                    path.emplace_back(kid, 0u);
+                continue;
+            }
+            uint32_t h = 0;
+            for (uint32_t k = 0; k < nKids; ++k)
+                h = std::max<uint32_t>(h, height[words[at + 1 + k]]);
+            if (h + 1 > 23)
+                return fail(c, PGPU_ERR_DEPTH, "pgpu_upload_svdags: DAG taller than CAST_STACK_DEPTH (23)");
+            height[at] = uint8_t(h + 1);
+            state[at] = 2;
+            path.pop_back();
         }
+        levels = std::max<uint32_t>(levels, height[dags[d].root]);
     }
     std::vector<SvdagDev> dev(n_dags);
     for (size_t d = 0; d < n_dags; ++d) {
@@ -108,6 +125,7 @@ int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const
     c->top.dagWords = dw;
     c->top.dags = dd;
     c->top.n_dags = uint32_t(n_dags);
+    c->top.dag_levels = levels;
     return PGPU_OK;
 }
 
@@ -206,7 +224,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         off += alignUp(bytes);
         return at;
     };
-    const size_t oNode = carve(n * 4), oStack = carve(n * 8), oParkedRay = carve(n * 4), oParkedLeaf = carve(n * 4);
+    const size_t oNode = carve(n * 4), oStack = carve(n * 8), oWorkRayAlt = carve(n * 4), oParkedLeaf = carve(n * 4);
     const size_t oWorkRay = carve(n * 4), oWorkBvh = carve(n * 4), oWorkLeaf = carve(n * 4);
     const size_t oLeafCount = carve(nl * 4), oLeafStart = carve(nl * 4), oLeafFill = carve(nl * 4);
     const size_t oParkedCount = carve(256), oCounters = carve(256);
@@ -221,7 +239,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     unsigned char* wb = static_cast<unsigned char*>(c->work.ptr);
     uint32_t* dNode = reinterpret_cast<uint32_t*>(wb + oNode);
     uint64_t* dStack = reinterpret_cast<uint64_t*>(wb + oStack);
-    uint32_t* dParkedRay = reinterpret_cast<uint32_t*>(wb + oParkedRay);
+    uint32_t* dWorkRayAlt = reinterpret_cast<uint32_t*>(wb + oWorkRayAlt); // the work list is double buffered: binning reads one, writes the other
     uint32_t* dParkedLeaf = reinterpret_cast<uint32_t*>(wb + oParkedLeaf);
     uint32_t* dWorkRay = reinterpret_cast<uint32_t*>(wb + oWorkRay);
     uint32_t* dWorkBvh = reinterpret_cast<uint32_t*>(wb + oWorkBvh);
@@ -284,8 +302,6 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ta.stack = dStack;
     ta.visits = dVisits;
     ta.any_out = dAny;
-    ta.parked_count = dParkedCount;
-    ta.parked_ray = dParkedRay;
     ta.parked_leaf = dParkedLeaf;
     ta.leaf_count = dLeafCount;
     ta.counters = dCounters;
@@ -320,13 +336,20 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     uint64_t rounds = 0, leafVisits = 0;
     uint32_t nActive = uint32_t(n);
     const uint32_t* active = nullptr; // round 0: every ray, identity order
-    const uint32_t topMaxBlocks = uint32_t(c->numCUs) * 2u;
+    // blocks of 256 per CU the top-level kernel can keep resident: LDS (160 KiB) and registers (<= 80 VGPRs: 6 waves per SIMD)
+    const uint32_t topPerCU = uint32_t(std::max<size_t>(1, std::min<size_t>(6, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
+    const uint32_t topMaxBlocks = uint32_t(c->numCUs) * topPerCU;
     while (nActive > 0) {
-        HIP_TRY(c, hipMemsetAsync(dParkedCount, 0, 4, stream));
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
         ta.active = active;
         ta.n_active = nActive;
         HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u)), stream));
+        // The scan and the binning do not depend on the host knowing the count: queue them behind the traversal,
+        // then fetch the number of parked rays (it sizes the bottom-level launch and ends the loop).
+        HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), dParkedCount, stream));
+        uint32_t* const workRayOut = (active == dWorkRay) ? dWorkRayAlt : dWorkRay; // binning reads the current list
+        HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, nActive, dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
+                       std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nActive + 255u) / 256u)), stream));
         uint32_t parked = 0;
         HIP_TRY(c, hipMemcpyAsync(&parked, dParkedCount, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(c, hipStreamSynchronize(stream));
@@ -334,9 +357,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             break;
         ++rounds;
         leafVisits += parked;
-        HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), stream));
-        HIP_TRY(c, launchBinByLeaf(dParkedRay, dParkedLeaf, dParkedCount, dLeafStart, dLeafFill, c->top.leaves, dWorkRay, dWorkBvh, dWorkLeaf,
-                       std::max(1u, std::min(uint32_t(c->numCUs) * 4u, (parked + 255u) / 256u)), stream));
+        ba.work_ray = workRayOut;
         HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
         ba.n_work = parked;
         uint32_t blocks = 1;
@@ -344,7 +365,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         if (rc != PGPU_OK)
             return rc;
         HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
-        active = dWorkRay;
+        active = workRayOut;
         nActive = parked;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));

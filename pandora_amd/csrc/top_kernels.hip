@@ -81,7 +81,7 @@ __device__ bool svdagHit(const uint32_t* __restrict__ words, const SvdagDev& dag
         if (valid >> child & 1u) {
             // PUSH
             const float half = exp2i((scale - 1) - kCastDepth);
-            saved[uint32_t(scale) * savedStride] = parent;
+            saved[uint32_t(kCastDepth - 1 - scale) * savedStride] = parent;
             if ((valid & leaf) >> child & 1u)
                 return true;
             const uint32_t inner = valid & ~leaf;
@@ -117,7 +117,7 @@ __device__ bool svdagHit(const uint32_t* __restrict__ words, const SvdagDev& dag
                         diff |= __float_as_uint(pos[i]) ^ __float_as_uint(pos[i] + size);
                 scale = 31 - __clz(int(diff));
                 if (scale < kCastDepth)
-                    parent = saved[uint32_t(scale) * savedStride];
+                    parent = saved[uint32_t(kCastDepth - 1 - scale) * savedStride];
             }
             uint32_t sh[3];
 #pragma unroll
@@ -182,8 +182,10 @@ __device__ __forceinline__ KeyGroup groupByKey(uint32_t key, bool active)
 template <bool ANY, bool NODES_IN_LDS>
 __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
 {
-    __shared__ __align__(16) unsigned char ldsNodes[NODES_IN_LDS ? kTopLdsNodeBudget : 16];
-    __shared__ uint32_t dagStack[(kCastDepth + 1) * kTopBlock];
+    // dynamic LDS: [dag_levels x 256 saved parents of the SVDAG cast][the top-level nodes, when they fit]
+    extern __shared__ __align__(16) unsigned char topLds[];
+    uint32_t* const dagStack = reinterpret_cast<uint32_t*>(topLds);
+    unsigned char* const ldsNodes = topLds + size_t(a.top.dag_levels) * kTopBlock * 4u;
     if (NODES_IN_LDS) {
         const uint32_t words = a.top.n_nodes * (kTopNodeBytes / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.top.nodes);
@@ -285,22 +287,13 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
                 a.visits[ray] += 1u; // Ray::numTopLevelIntersections (:283)
         }
         }
-        // park: one slot per ray in the round's list, one count per batching point
-        const uint64_t parkedMask = __ballot(parked);
-        if (parkedMask != 0) {
-            const uint32_t lane = threadIdx.x & 63u;
-            uint32_t base = 0;
-            if (lane == uint32_t(__builtin_ctzll(parkedMask)))
-                base = atomicAdd(a.parked_count, uint32_t(__popcll(parkedMask)));
-            base = uint32_t(__builtin_amdgcn_readlane(int(base), __builtin_ctzll(parkedMask)));
+        // park: the round's list keeps one entry per work item (the batching point, or none), one count per point
+        if (live)
+            a.parked_leaf[w] = parked ? leafId : PGPU_MISS_ID;
+        if (__ballot(parked) != 0) {
             const KeyGroup kg = groupByKey(leafId, parked);
-            if (parked) {
-                const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(uint32_t(parkedMask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(parkedMask), 0u));
-                a.parked_ray[slot] = ray;
-                a.parked_leaf[slot] = leafId;
-                if (kg.leader == lane)
-                    atomicAdd(&a.leaf_count[leafId], kg.size);
-            }
+            if (parked && kg.leader == (threadIdx.x & 63u))
+                atomicAdd(&a.leaf_count[leafId], kg.size);
         }
     }
     if (nTests)
@@ -311,7 +304,7 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
 
 // exclusive scan of leaf_count into leaf_start (single block; batching points number in the hundreds)
 __global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
-    uint32_t* __restrict__ fill, uint32_t n)
+    uint32_t* __restrict__ fill, uint32_t n, uint32_t* __restrict__ total)
 {
     __shared__ uint32_t part[1024];
     const uint32_t per = (n + 1023u) / 1024u;
@@ -333,19 +326,20 @@ __global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* __restric
         fill[i] = 0;
         run += count[i];
     }
+    if (threadIdx.x == 1023)
+        *total = part[1023]; // rays parked in this round
 }
 
 // scatter parked records into per-leaf contiguous ranges (the GPU form of the per-leaf queues)
-__global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restrict__ parkedRay, const uint32_t* __restrict__ parkedLeaf,
-    const uint32_t* __restrict__ parkedCount, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
+__global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf,
+    uint32_t n, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
     const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf)
 {
-    const uint32_t n = *parkedCount;
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {
         const uint32_t i = i0 + threadIdx.x;
-        const bool live = i < n;
-        const uint32_t leaf = live ? parkedLeaf[i] : 0u;
+        const uint32_t leaf = i < n ? parkedLeaf[i] : PGPU_MISS_ID;
+        const bool live = leaf != PGPU_MISS_ID;
         const KeyGroup kg = groupByKey(leaf, live);
         uint32_t base = 0;
         if (live && kg.leader == lane)
@@ -353,7 +347,7 @@ __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restric
         base = uint32_t(__builtin_amdgcn_ds_bpermute(int(kg.leader << 2), int(base)));
         if (live) {
             const uint32_t at = leafStart[leaf] + base + kg.rank;
-            workRay[at] = parkedRay[i];
+            workRay[at] = active ? active[i] : i;
             workBvh[at] = leaves[leaf].bvh;
             workLeaf[at] = leaf;
         }
@@ -384,34 +378,40 @@ __global__ __launch_bounds__(256) void initStateKernel(uint32_t n, uint32_t root
 
 bool topNodesFitLds(uint32_t nNodes) { return size_t(nNodes) * kTopNodeBytes <= kTopLdsNodeBudget; }
 
+size_t topTraverseLdsBytes(const TopDev& top)
+{
+    return size_t(top.dag_levels) * kTopBlock * 4u + (topNodesFitLds(top.n_nodes) ? ((size_t(top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u);
+}
+
 hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream)
 {
     const bool inLds = topNodesFitLds(a.top.n_nodes);
     const dim3 grid(blocks), block(kTopBlock);
+    const size_t ldsBytes = topTraverseLdsBytes(a.top);
     if (kind == PGPU_ANY_ID) {
         if (inLds)
-            hipLaunchKernelGGL((topTraverseKernel<true, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((topTraverseKernel<true, true>), grid, block, ldsBytes, stream, a);
         else
-            hipLaunchKernelGGL((topTraverseKernel<true, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((topTraverseKernel<true, false>), grid, block, ldsBytes, stream, a);
     } else {
         if (inLds)
-            hipLaunchKernelGGL((topTraverseKernel<false, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((topTraverseKernel<false, true>), grid, block, ldsBytes, stream, a);
         else
-            hipLaunchKernelGGL((topTraverseKernel<false, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((topTraverseKernel<false, false>), grid, block, ldsBytes, stream, a);
     }
     return hipGetLastError();
 }
 
-hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, hipStream_t stream)
+hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream)
 {
-    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, count, start, fill, n);
+    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, count, start, fill, n, total);
     return hipGetLastError();
 }
 
-hipError_t launchBinByLeaf(const uint32_t* parkedRay, const uint32_t* parkedLeaf, const uint32_t* parkedCount, const uint32_t* leafStart,
+hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, parkedRay, parkedLeaf, parkedCount, leafStart, leafFill, leaves,
+    hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, leafStart, leafFill, leaves,
         workRay, workBvh, workLeaf);
     return hipGetLastError();
 }
