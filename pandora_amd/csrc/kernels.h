@@ -93,7 +93,7 @@ bool topNodesFitLds(uint32_t nNodes);
 hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream);
 size_t topTraverseLdsBytes(const TopDev& top);
 hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream);
-hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, const uint32_t* leafStart,
+hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream);
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);

@@ -348,7 +348,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         // then fetch the number of parked rays (it sizes the bottom-level launch and ends the loop).
         HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), dParkedCount, stream));
         uint32_t* const workRayOut = (active == dWorkRay) ? dWorkRayAlt : dWorkRay; // binning reads the current list
-        HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, nActive, dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
+        HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, nActive, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
                        std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nActive + 255u) / 256u)), stream));
         uint32_t parked = 0;
         HIP_TRY(c, hipMemcpyAsync(&parked, dParkedCount, 4, hipMemcpyDeviceToHost, stream));

@@ -27,6 +27,7 @@ namespace {
 constexpr uint32_t kTopBlock = 256;
 constexpr uint32_t kTopNodeBytes = 112;
 constexpr uint32_t kTopLdsNodeBudget = 40 * 1024; // nodes staged in LDS when they fit
+constexpr uint32_t kTopHistMax = 4096;             // batching points whose per-block counters fit LDS
 constexpr int kCastDepth = 23;                     // CAST_STACK_DEPTH, sparse_voxel_dag.cpp:311
 
 __device__ __forceinline__ float min86(float a, float b) { return a < b ? a : b; }
@@ -183,17 +184,22 @@ template <bool ANY, bool NODES_IN_LDS>
 __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
 {
     // dynamic LDS: [dag_levels x 256 saved parents of the SVDAG cast][the top-level nodes, when they fit]
+    // [2 SVDAG counters + one counter per batching point, when they fit]
     extern __shared__ __align__(16) unsigned char topLds[];
     uint32_t* const dagStack = reinterpret_cast<uint32_t*>(topLds);
     unsigned char* const ldsNodes = topLds + size_t(a.top.dag_levels) * kTopBlock * 4u;
+    uint32_t* const ldsCount = reinterpret_cast<uint32_t*>(ldsNodes + (NODES_IN_LDS ? ((size_t(a.top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u));
+    const bool countInLds = a.top.n_leaves <= kTopHistMax;
     if (NODES_IN_LDS) {
         const uint32_t words = a.top.n_nodes * (kTopNodeBytes / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.top.nodes);
         uint32_t* dst = reinterpret_cast<uint32_t*>(ldsNodes);
         for (uint32_t i = threadIdx.x; i < words; i += kTopBlock)
             dst[i] = src[i];
-        __syncthreads();
     }
+    for (uint32_t i = threadIdx.x; i < 2u + (countInLds ? a.top.n_leaves : 0u); i += kTopBlock)
+        ldsCount[i] = 0u;
+    __syncthreads();
     const unsigned char* nodeBase = NODES_IN_LDS ? ldsNodes : a.top.nodes;
     uint32_t nTests = 0, nCulled = 0;
 
@@ -292,14 +298,26 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
             a.parked_leaf[w] = parked ? leafId : PGPU_MISS_ID;
         if (__ballot(parked) != 0) {
             const KeyGroup kg = groupByKey(leafId, parked);
-            if (parked && kg.leader == (threadIdx.x & 63u))
-                atomicAdd(&a.leaf_count[leafId], kg.size);
+            if (parked && kg.leader == (threadIdx.x & 63u)) {
+                if (countInLds)
+                    atomicAdd(&ldsCount[2u + leafId], kg.size);
+                else
+                    atomicAdd(&a.leaf_count[leafId], kg.size);
+            }
         }
     }
+    // one global update per block and counter instead of one per ray: same-address atomics serialise in L2
     if (nTests)
-        atomicAdd(&a.counters[0], (unsigned long long)nTests);
+        atomicAdd(&ldsCount[0], nTests);
     if (nCulled)
-        atomicAdd(&a.counters[1], (unsigned long long)nCulled);
+        atomicAdd(&ldsCount[1], nCulled);
+    __syncthreads();
+    if (threadIdx.x < 2u && ldsCount[threadIdx.x] != 0u)
+        atomicAdd(&a.counters[threadIdx.x], (unsigned long long)ldsCount[threadIdx.x]);
+    if (countInLds)
+        for (uint32_t i = threadIdx.x; i < a.top.n_leaves; i += kTopBlock)
+            if (ldsCount[2u + i] != 0u)
+                atomicAdd(&a.leaf_count[i], ldsCount[2u + i]);
 }
 
 // exclusive scan of leaf_count into leaf_start (single block; batching points number in the hundreds)
@@ -354,6 +372,60 @@ __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restric
     }
 }
 
+// Same, for scenes whose batching points fit LDS: a block owns a contiguous slice of the round's list, counts it per
+// point in LDS, reserves one range per point it saw with a single global atomic, and hands out the slots from LDS.
+__global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf,
+    uint32_t n, uint32_t nLeaves, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
+    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf)
+{
+    extern __shared__ uint32_t binLds[]; // [nLeaves] running count, [nLeaves] first slot of this block's range
+    uint32_t* const cnt = binLds;
+    uint32_t* const first = binLds + nLeaves;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t per = (((n + gridDim.x - 1u) / gridDim.x) + 255u) & ~255u;
+    const uint32_t lo = min(blockIdx.x * per, n), hi = min(lo + per, n);
+    for (uint32_t i = threadIdx.x; i < nLeaves; i += 256u)
+        cnt[i] = 0u;
+    __syncthreads();
+    for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t leaf = i < hi ? parkedLeaf[i] : PGPU_MISS_ID;
+        const bool live = leaf != PGPU_MISS_ID;
+        if (__ballot(live) != 0) {
+            const KeyGroup kg = groupByKey(leaf, live);
+            if (live && kg.leader == lane)
+                atomicAdd(&cnt[leaf], kg.size);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nLeaves; i += 256u) {
+        const uint32_t c = cnt[i];
+        if (c != 0u) {
+            first[i] = leafStart[i] + atomicAdd(&leafFill[i], c);
+            cnt[i] = 0u;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t leaf = i < hi ? parkedLeaf[i] : PGPU_MISS_ID;
+        const bool live = leaf != PGPU_MISS_ID;
+        if (__ballot(live) == 0)
+            continue;
+        const KeyGroup kg = groupByKey(leaf, live);
+        uint32_t off = 0;
+        if (live && kg.leader == lane)
+            off = atomicAdd(&cnt[leaf], kg.size);
+        off = uint32_t(__builtin_amdgcn_ds_bpermute(int(kg.leader << 2), int(off)));
+        if (live) {
+            const uint32_t at = first[leaf] + off + kg.rank;
+            workRay[at] = active ? active[i] : i;
+            workBvh[at] = leaves[leaf].bvh;
+            workLeaf[at] = leaf;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void initStateKernel(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn,
     float* tState, uint32_t* obj, uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut)
 {
@@ -380,7 +452,8 @@ bool topNodesFitLds(uint32_t nNodes) { return size_t(nNodes) * kTopNodeBytes <= 
 
 size_t topTraverseLdsBytes(const TopDev& top)
 {
-    return size_t(top.dag_levels) * kTopBlock * 4u + (topNodesFitLds(top.n_nodes) ? ((size_t(top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u);
+    return size_t(top.dag_levels) * kTopBlock * 4u + (topNodesFitLds(top.n_nodes) ? ((size_t(top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u)
+        + 8u + (top.n_leaves <= kTopHistMax ? size_t(top.n_leaves) * 4u : 0u);
 }
 
 hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream)
@@ -408,9 +481,14 @@ hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill
     return hipGetLastError();
 }
 
-hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, const uint32_t* leafStart,
+hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream)
 {
+    if (nLeaves <= kTopHistMax) {
+        hipLaunchKernelGGL(binByLeafLdsKernel, dim3(blocks), dim3(256), size_t(nLeaves) * 8u, stream, active, parkedLeaf, nActive, nLeaves, leafStart,
+            leafFill, leaves, workRay, workBvh, workLeaf);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, leafStart, leafFill, leaves,
         workRay, workBvh, workLeaf);
     return hipGetLastError();
