@@ -221,7 +221,7 @@ __device__ __forceinline__ void ldsStoreU4(lds_u8* p, uint32_t x, uint32_t y, ui
 }
 
 template <bool ANY, int TRI, bool STATS>
-__global__ __launch_bounds__(256) void bvh8TraceKernel(Bvh8TraceArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void bvh8TraceKernel(Bvh8TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char ldsGeneric[];
     lds_u8* const lds = (lds_u8*)ldsGeneric;

@@ -105,17 +105,17 @@ inline uint32_t stackEntriesForDepth(uint32_t depth)
     return need < 16u ? 16u : ((need + 7u) & ~7u);
 }
 // LDS window of the per-ray stack: the whole worst case when it is small, otherwise a window sized so that
-// 6 blocks fit a CU; deeper entries spill to global memory.
+// 7 blocks fit a CU; deeper entries spill to global memory.
 inline uint32_t stackWindow(uint32_t need, int requested)
 {
-    const uint32_t cap = requested > 0 ? uint32_t(requested) : 18u;
+    const uint32_t cap = requested > 0 ? uint32_t(requested) : 11u;
     return need < cap ? need : cap;
 }
 // blocks of 256 threads per CU: requested, or (0) as many as LDS (160 KiB) and registers allow
 inline uint32_t blocksPerCU(int requested, uint32_t stackEntries)
 {
     const uint32_t byLds = uint32_t((160u * 1024u) / ((bvh8TraceLdsBytes(stackEntries) + 1023u) & ~size_t(1023))); // LDS is handed out in coarse granules
-    const uint32_t byRegs = 6u; // <= 80 VGPRs
+    const uint32_t byRegs = 7u; // <= 72 VGPRs
     const uint32_t cap = byLds < byRegs ? byLds : byRegs;
     if (requested <= 0)
         return cap < 1u ? 1u : cap;

@@ -24,7 +24,7 @@ o2 = ctx.trace_bvh8(bvh, ddiff); ctx.sync()
 print("diffuse (stats on): %.3f ms, %.1f Mrays/s" % (ctx.last_kernel_ms(), n / ctx.last_kernel_ms() / 1e3), ctx.counters(), flush=True)
 lpr = 4
 for rmin, bpc, chunk, win, lmin in ((3, 0, 64, 0, 0), (2, 0, 64, 0, 0), (4, 0, 64, 0, 0), (6, 0, 64, 0, 0), (3, 0, 64, 0, 2), (3, 0, 64, 0, 3), (3, 0, 64, 0, 5), (3, 0, 64, 0, 6),
-                                 (3, 0, 64, 8, 0), (3, 0, 64, 12, 0), (3, 0, 64, 16, 0), (3, 0, 64, 21, 0), (3, 0, 64, 28, 0), (3, 0, 64, 64, 0), (3, 4, 64, 0, 0), (3, 0, 32, 0, 0), (3, 0, 128, 0, 0)):
+                                 (3, 0, 64, 8, 0), (3, 0, 64, 11, 0), (3, 0, 64, 12, 0), (3, 0, 64, 16, 0), (3, 0, 64, 21, 0), (3, 0, 64, 28, 0), (3, 0, 64, 64, 0), (3, 4, 64, 0, 0), (3, 0, 32, 0, 0), (3, 0, 128, 0, 0)):
     ctx.set_kernel_variant(rmin, win, lmin)
     ctx.set_tuning(bpc, chunk)
     ctx.set_stats(True)
