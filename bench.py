@@ -134,6 +134,15 @@ def main() -> None:
                    "sample": f"first {sample} rays of the same R-diffuse batch, oracle/pandora_oracle.c (scalar restatement of WiVeBVH8::intersect), {threads} pthreads",
                    "gpu_matches_bit_exact": bool(same),
                    "visits_per_ray": {k: want["counters"][k] / sample for k in ("inner_visits", "leaf_pops", "tri_tests")}}
+        # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command
+        # (tools/pmc_passes.sh), which cannot run inside the timed process; the committed summary is quoted.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if args.kind == "closest" and os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("rays_per_launch") == n:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/pmc_traffic.json (" + tj["how"] + ")"
         line = {
             "metric": "Mrays/s incoherent diffuse rays", "value": value, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -142,7 +151,7 @@ def main() -> None:
                        "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
                        "triangle_test": "moller-trumbore", "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "scene_bytes": scene_bytes},
             "cpu_baseline": cpu,
         }

@@ -19,5 +19,5 @@ for GROUP in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
   echo "pass $i [$GROUP] rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 "$OUT/p$i.log"; exit $rc; fi
 done
-python3 "$R/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+python3 "$R/tools/pmc_summary.py" "$OUT" "$OUT/pmc_traffic.json" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

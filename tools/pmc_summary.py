@@ -4,13 +4,21 @@ from collections import defaultdict
 
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True):
+import re
+for d in sorted(glob.glob(os.path.join(root, "p*"))):
+    if not os.path.isdir(d):
+        continue
+    found = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if not found:
+        continue
+    f = found[-1]  # a pass directory that was reused keeps older runs: only the newest counts
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row["Kernel_Name"]
             if "rocclr" in k:
                 continue
-            short = k.split("(")[0].split("::")[-1]
+            m = re.search(r"(\w+Kernel)", k)
+            short = m.group(1) if m else k[:40]
             acc[short][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
 for kern, ctrs in acc.items():
     print(kern)
@@ -18,3 +26,29 @@ for kern, ctrs in acc.items():
         vals = [v for _, v in sorted(ctrs[name])]
         tail = vals[1:] if len(vals) > 1 else vals  # first dispatch of bench.py is the primary-ray pass
         print("  %-32s n=%d mean(all but first)=%.6g  last=%.6g" % (name, len(vals), sum(tail) / len(tail), vals[-1]))
+
+# HBM-side traffic of the dominant kernel, per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are
+# KiB at the L2's memory side; on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64
+# bytes, so it is doubled; WRITE_SIZE is exact). Infinity-Cache hits are included in both.
+if len(sys.argv) > 2 and "bvh8TraceKernel" in acc:
+    import json
+    c = acc["bvh8TraceKernel"]
+    def rays_per_launch():
+        import re
+        for lf in sorted(glob.glob(os.path.join(root, "p*.log"))):
+            m = re.search(r'"rays_per_gpu": (\d+)', open(lf, errors="replace").read())
+            if m:
+                return int(m.group(1))
+        return None
+    def mean_tail(name):
+        vals = [v for _, v in sorted(c[name])]
+        tail = vals[1:] if len(vals) > 1 else vals
+        return sum(tail) / len(tail)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        f, w = mean_tail("FETCH_SIZE"), mean_tail("WRITE_SIZE")
+        out = {"fetch_size_kib": f, "write_size_kib": w, "traffic_bytes_per_launch": int((2.0 * f + w) * 1024),
+               "rays_per_launch": rays_per_launch(),
+               "how": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over bench.py, mean over the timed launches; (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 half-count correction for 16-byte-per-lane reads; includes Infinity Cache hits"}
+        with open(sys.argv[2], "w") as fh:
+            json.dump(out, fh, indent=1)
+        print("traffic json ->", sys.argv[2], out["traffic_bytes_per_launch"])
