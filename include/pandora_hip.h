@@ -39,6 +39,7 @@ enum { PGPU_TRI_MT = 0, PGPU_TRI_WATERTIGHT = 1 }; /* triangle_intersect.cpp:425
 enum { PGPU_MEM_HOST = 0, PGPU_MEM_DEVICE = 1 };   /* where ray / hit arrays live */
 #define PGPU_MISS 0xFFFFFFFFu
 #define PGPU_NO_SVDAG 0xFFFFFFFFu
+#define PGPU_NO_BVH 0xFFFFFFFFu /* pgpu_leaf.bvh_id of a batching point whose geometry lives on another GPU */
 
 typedef struct pgpu_ctx pgpu_ctx;
 
@@ -165,6 +166,25 @@ int pgpu_trace_bvh8(pgpu_ctx*, uint32_t bvh_id, int kind, int tri_mode, const pg
  * points, per-leaf bottom-level traversal, resume -- until every ray has exited. */
 int pgpu_trace(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
     const pgpu_hits* hits, uint32_t* any_hit, pgpu_counters* counters, void* stream);
+
+/* ---- building blocks of pgpu_trace, for loops that span several GPUs (leaves sharded over HBM).
+ * All arrays are device memory; the calls queue work on `stream` (NULL = the context's stream) and return.
+ *
+ * pgpu_ray_state_init: PauseableBVH4 start token {root, ~0} (pauseable_bvh4.h:202) for n rays, t = tfar, miss records.
+ * pgpu_top_episode:    PauseableBVH4::intersectT (pauseable_bvh4.h:225-355) from each listed ray's token to its next
+ *                      batching point (SVDAG test included, offline_batching...h:269-305) or to the exit.
+ *                      active = ray ids to advance (NULL: 0..n_active-1); parked_leaf[i] = batching point work item i
+ *                      parked at, or PGPU_MISS. t_state = current ray.tfar per ray (closest hit); any_out = occlusion
+ *                      flags (any hit; occluded rays are skipped). SVDAG counters accumulate in the context.
+ * pgpu_trace_leaves:   the leaf tasks (offline_batching...h:179-205, :226-259) without the resume: work item i
+ *                      sends ray work_ray[i] through the bottom-level BVH of batching point work_leaf[i], which must be
+ *                      resident here. Closest hit: hits->t is read as the ray's tfar and, like obj/leaf/u/v, written
+ *                      only when the leaf yields a closer hit. Any hit: any_hit[ray] = 1 on a hit. */
+int pgpu_ray_state_init(pgpu_ctx*, size_t n, const float* tfar, uint32_t* node, uint64_t* stack, const pgpu_hits* hits, uint32_t* any_hit, void* stream);
+int pgpu_top_episode(pgpu_ctx*, int kind, const pgpu_rays* rays, const uint32_t* active, size_t n_active, uint32_t* node, uint64_t* stack,
+    const float* t_state, uint32_t* visits, uint32_t* any_hit, uint32_t* parked_leaf, void* stream);
+int pgpu_trace_leaves(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, const uint32_t* work_ray, const uint32_t* work_leaf,
+    size_t n_work, const pgpu_hits* hits, uint32_t* any_hit, void* stream);
 
 /* Diagnostics: device time of the traversal kernels of the last trace call on this context, measured
  * with HIP events on the stream they ran on (ms); enables/disables visit counters. */

@@ -256,6 +256,28 @@ class Context:
             _check(self._L.pgpu_trace(self._h, kind, tri_mode, C.byref(r), n, mem, C.byref(h), capi.ptr(out["hit"]), C.byref(cnt), stream), self._h)
         return out, {f: int(getattr(cnt, f)) for f, _ in capi.Counters._fields_}
 
+    # -- building blocks of the two-level loop (device tensors only; used by pandora_amd.sharded)
+    def ray_state_init(self, tfar, node, stack, hits: dict | None, any_hit=None, stream: int = 0):
+        n = int(node.shape[0])
+        h = None
+        if hits is not None:
+            h = capi.Hits(capi.ptr(hits["t"]), capi.ptr(hits["obj"]), capi.ptr(hits["leaf"]), capi.ptr(hits["u"]), capi.ptr(hits["v"]), capi.ptr(hits.get("visits")))
+        _check(self._L.pgpu_ray_state_init(self._h, n, capi.ptr(tfar), capi.ptr(node), capi.ptr(stack), C.byref(h) if h is not None else None,
+                                           capi.ptr(any_hit), stream), self._h)
+
+    def top_episode(self, kind: int, rays, active, n_active: int, node, stack, t_state, visits, any_hit, parked_leaf, stream: int = 0):
+        r, _ = self._rays_struct(rays)
+        _check(self._L.pgpu_top_episode(self._h, kind, C.byref(r), capi.ptr(active), n_active, capi.ptr(node), capi.ptr(stack), capi.ptr(t_state),
+                                        capi.ptr(visits), capi.ptr(any_hit), capi.ptr(parked_leaf), stream), self._h)
+
+    def trace_leaves(self, kind: int, tri_mode: int, rays, work_ray, work_leaf, n_work: int, hits: dict | None, any_hit=None, stream: int = 0):
+        r, _ = self._rays_struct(rays)
+        h = None
+        if hits is not None:
+            h = capi.Hits(capi.ptr(hits["t"]), capi.ptr(hits["obj"]), capi.ptr(hits["leaf"]), capi.ptr(hits["u"]), capi.ptr(hits["v"]), 0)
+        _check(self._L.pgpu_trace_leaves(self._h, kind, tri_mode, C.byref(r), capi.ptr(work_ray), capi.ptr(work_leaf), n_work,
+                                         C.byref(h) if h is not None else None, capi.ptr(any_hit), stream), self._h)
+
     def sync(self, stream: int = 0):
         _check(self._L.pgpu_sync(self._h, stream), self._h)
 
@@ -292,9 +314,15 @@ class TwoLevelScene:
     def n_leaves(self) -> int:
         return len(self.groups)
 
-    def upload(self, ctx: "Context", mesh_id: int):
-        """Uploads BVHs, SVDAGs and the top level. Returns bvh ids in final leaf-slot order."""
-        ids = [ctx.upload_bvh8(b, mesh_id) for b in self.bvhs]
+    def upload(self, ctx: "Context", mesh_id: int, resident=None):
+        """Uploads BVHs, SVDAGs and the top level. Returns bvh ids in final leaf-slot order.
+
+        resident: optional bool array over leaf slots -- only those batching points' bottom-level BVHs are
+        uploaded (leaves sharded over several GPUs); the others are marked NO_BVH. The top level and the
+        SVDAGs are small and always uploaded whole."""
+        slot_of = np.empty(self.n_leaves, np.int64)
+        slot_of[np.asarray(self.top.leaf_order, np.int64)] = np.arange(self.n_leaves)
+        ids = [ctx.upload_bvh8(b, mesh_id) if (resident is None or bool(resident[slot_of[i]])) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
         if self.dags is not None:
             ctx.upload_svdags(self.dags)
         leaves = np.empty((self.n_leaves, 2), np.uint32)

@@ -19,6 +19,7 @@ TRI_MT, TRI_WATERTIGHT = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MISS = 0xFFFFFFFF
 NO_SVDAG = 0xFFFFFFFF
+NO_BVH = 0xFFFFFFFF
 
 c_f32p = C.POINTER(C.c_float)
 c_u32p = C.POINTER(C.c_uint32)
@@ -81,6 +82,9 @@ SYMBOLS = {
     "pgpu_upload_top_bvh4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),
     "pgpu_trace_bvh8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.c_int, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
     "pgpu_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.c_int, C.POINTER(Hits), C.c_void_p, C.POINTER(Counters), C.c_void_p]),
+    "pgpu_ray_state_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
+    "pgpu_top_episode": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Rays), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgpu_trace_leaves": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
     "pgpu_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "pgpu_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgpu_set_stats": (C.c_int, [C.c_void_p, C.c_int]),

@@ -144,6 +144,7 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a,
     const uint32_t window = stackWindow(need, c->stackWindow);
     a.stack_entries = window;
     a.refill_min = c->refillMin;
+    a.n_bvhs = uint32_t(c->bvhs.size());
     a.range_size = uint32_t((((n_work + 7) / 8 + a.chunk - 1) / a.chunk) * a.chunk);
     a.leaf_min = c->leafMin ? c->leafMin : 4u;
     a.spill_entries = need > window ? need - window : 0u;
@@ -194,6 +195,10 @@ int pgpu_init(int device_id, pgpu_ctx** out)
         e = hipMalloc(reinterpret_cast<void**>(&c->statsDev), 64);
     if (e == hipSuccess)
         e = hipMemset(c->statsDev, 0, 64);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&c->topCounters), 64);
+    if (e == hipSuccess)
+        e = hipMemset(c->topCounters, 0, 64);
     hipDeviceProp_t prop;
     if (e == hipSuccess)
         e = hipGetDeviceProperties(&prop, device_id);
@@ -220,7 +225,9 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipFree(c->cursor);
     if (c->statsDev)
         (void)hipFree(c->statsDev);
-    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill })
+    if (c->topCounters)
+        (void)hipFree(c->topCounters);
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork })
         if (b->ptr)
             (void)hipFree(b->ptr);
     (void)hipEventDestroy(c->ev0);
@@ -465,6 +472,15 @@ int pgpu_sync(pgpu_ctx* c, void* stream_)
     HIP_TRY(c, hipStreamSynchronize(stream));
     if (hipEventQuery(c->ev1) == hipSuccess)
         (void)hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1);
+    if (c->topCountersDirty) {
+        // SVDAG counters of the pgpu_top_episode calls since the last sync (g_stats.svdag.*): they accumulate
+        unsigned long long t[2] = { 0, 0 };
+        HIP_TRY(c, hipMemcpy(t, c->topCounters, sizeof(t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemset(c->topCounters, 0, 64));
+        c->counters.svdag_tests += t[0];
+        c->counters.svdag_culled += t[1];
+        c->topCountersDirty = false;
+    }
     if (c->stats) {
         const int rs = pandora_hip::readKernelStats(c);
         if (rs != PGPU_OK)

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 rayId = a.work_ray ? a.work_ray[w] : w;
                 const uint32_t bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
                 tag = a.work_tag ? a.work_tag[w] : 0u;
-                const Bvh8Dev bd = a.bvhs[bvhId];
+                const Bvh8Dev bd = a.bvhs[min(bvhId, a.n_bvhs - 1u)];
                 nodePiece = bd.nodes + myPiece16;
                 triMine = bd.tris + q * 48u;
                 // lane q of the quad loads component q of the origin and of the direction (lane 3: tnear, tfar)
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                     ldsStoreU2(stackBase, make_uint2(bd.root, __float_as_uint(0.0f))); // :80-82
                 sp = 1;
                 hitMark = 0;
-                st = 1;
+                st = bvhId < a.n_bvhs ? 1 : 0; // (a work item whose geometry is not resident here is dropped)
             }
             if (STATS)
                 statRefill += (lane == 0);

@@ -47,7 +47,11 @@ struct pgpu_ctx {
     // two-level state (top_kernels.hip)
     pandora_hip::TopDev top {};
     bool haveTop = false;
+    bool topHasRemoteLeaves = false;
+    bool topCountersDirty = false; // pgpu_top_episode ran since the counters were last read
     DeviceBuffer work; // per-ray traversal state + queues, grown on demand
+    DeviceBuffer blockWork; // scratch of the building-block entry points (work item -> bvh id)
+    unsigned long long* topCounters = nullptr; // SVDAG tests / culled of pgpu_top_episode calls (device)
 };
 
 namespace pandora_hip {

@@ -34,6 +34,7 @@ struct Bvh8TraceArgs {
     const uint32_t* work_bvh; // work item -> bvh id (nullptr: fixed_bvh)
     const uint32_t* work_tag; // work item -> value stored in leaf_out on a hit (nullptr: 0)
     uint32_t fixed_bvh;
+    uint32_t n_bvhs;   // work items naming a bvh id beyond this are skipped (geometry not resident here)
     uint32_t n_work;
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
     float* t_out;
@@ -95,6 +96,7 @@ size_t topTraverseLdsBytes(const TopDev& top);
 hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream);
 hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream);
+hipError_t launchLeafToBvh(const uint32_t* workLeaf, const TopLeafDev* leaves, uint32_t nLeaves, uint32_t* workBvh, uint32_t n, uint32_t blocks, hipStream_t stream);
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);
 

@@ -147,9 +147,11 @@ int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint
             return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: child, leaf or parent handle out of range");
     }
     std::vector<TopLeafDev> lv(n_leaves);
+    bool remote = false;
     for (size_t i = 0; i < n_leaves; ++i) {
-        if (leaves[i].bvh_id >= c->bvhs.size())
+        if (leaves[i].bvh_id != PGPU_NO_BVH && leaves[i].bvh_id >= c->bvhs.size())
             return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: leaf names an unknown bvh id");
+        remote = remote || leaves[i].bvh_id == PGPU_NO_BVH;
         if (leaves[i].svdag != PGPU_NO_SVDAG && leaves[i].svdag >= c->top.n_dags)
             return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: leaf names an unknown svdag");
         lv[i].bvh = leaves[i].bvh_id;
@@ -169,6 +171,7 @@ int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint
     c->top.n_nodes = uint32_t(n_nodes);
     c->top.n_leaves = uint32_t(n_leaves);
     c->haveTop = true;
+    c->topHasRemoteLeaves = remote;
     return PGPU_OK;
 }
 
@@ -179,6 +182,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace: null argument");
     if (!c->haveTop)
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace: no top-level structure uploaded");
+    if (c->topHasRemoteLeaves)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace: some batching points are not resident on this GPU (PGPU_NO_BVH); drive pgpu_top_episode / pgpu_trace_leaves from a sharded loop");
     if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace: kind must be PGPU_CLOSEST or PGPU_ANY");
     if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
@@ -398,6 +403,155 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     }
     if (counters)
         *counters = c->counters;
+    return PGPU_OK;
+}
+
+int pgpu_ray_state_init(pgpu_ctx* c, size_t n, const float* tfar, uint32_t* node, uint64_t* stack, const pgpu_hits* hits, uint32_t* any_hit, void* stream_)
+{
+    if (!c || !node || !stack || n > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_ray_state_init: null argument or batch too large");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_ray_state_init: no top-level structure uploaded");
+    if (hits && (!tfar || !hits->t || !hits->obj || !hits->leaf || !hits->u || !hits->v))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_ray_state_init: closest-hit state needs tfar, t, obj, leaf, u, v");
+    if (n == 0)
+        return PGPU_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    const uint32_t blocks = uint32_t(std::min<size_t>((n + 255) / 256, size_t(c->numCUs) * 8));
+    HIP_TRY(c, launchInitState(uint32_t(n), c->top.root, node, stack, tfar, hits ? hits->t : nullptr, hits ? hits->obj : nullptr,
+                   hits ? hits->leaf : nullptr, hits ? hits->u : nullptr, hits ? hits->v : nullptr, hits ? hits->visits : nullptr, any_hit, blocks, stream));
+    return PGPU_OK;
+}
+
+int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_t* active, size_t n_active, uint32_t* node, uint64_t* stack,
+    const float* t_state, uint32_t* visits, uint32_t* any_hit, uint32_t* parked_leaf, void* stream_)
+{
+    if (!c || !rays || !node || !stack || !parked_leaf)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: null argument");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_top_episode: no top-level structure uploaded");
+    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: kind must be PGPU_CLOSEST or PGPU_ANY");
+    if ((kind == PGPU_CLOSEST && !t_state) || (kind == PGPU_ANY && !any_hit))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: closest hit needs t_state, any hit needs any_hit");
+    const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, rays->tfar };
+    for (const float* p : rp)
+        if (!p)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: null ray array");
+    if (n_active > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: batch too large");
+    if (n_active == 0)
+        return PGPU_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    TopTraceArgs ta {};
+    ta.top = c->top;
+    ta.active = active;
+    ta.n_active = uint32_t(n_active);
+    ta.ox = rp[0];
+    ta.oy = rp[1];
+    ta.oz = rp[2];
+    ta.dx = rp[3];
+    ta.dy = rp[4];
+    ta.dz = rp[5];
+    ta.tnear = rp[6];
+    ta.tfar_in = rp[7];
+    ta.tfar_state = t_state;
+    ta.node = node;
+    ta.stack = stack;
+    ta.visits = visits;
+    ta.any_out = any_hit;
+    ta.parked_leaf = parked_leaf;
+    ta.leaf_count = nullptr;
+    ta.counters = c->topCounters;
+    const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(6, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
+    const uint32_t blocks = std::max(1u, std::min(uint32_t(c->numCUs) * perCU, uint32_t((n_active + 255) / 256)));
+    HIP_TRY(c, launchTopTraverse(ta, kind, blocks, stream));
+    c->topCountersDirty = true;
+    return PGPU_OK;
+}
+
+int pgpu_trace_leaves(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, const uint32_t* work_ray, const uint32_t* work_leaf,
+    size_t n_work, const pgpu_hits* hits, uint32_t* any_hit, void* stream_)
+{
+    if (!c || !rays || !work_ray || !work_leaf)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: null argument");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaves: no top-level structure uploaded");
+    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: kind must be PGPU_CLOSEST or PGPU_ANY");
+    if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: unknown triangle test");
+    if (kind == PGPU_CLOSEST && (!hits || !hits->t || !hits->obj || !hits->leaf || !hits->u || !hits->v))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: closest-hit needs t, obj, leaf, u, v arrays");
+    if (kind == PGPU_ANY && !any_hit)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: any-hit needs the any_hit array");
+    const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, rays->tfar };
+    for (const float* p : rp)
+        if (!p)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: null ray array");
+    if (n_work > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: batch too large");
+    if (n_work == 0)
+        return PGPU_OK;
+    if (c->bvhs.empty())
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaves: no bottom-level BVH is resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->bvhTableDirty) {
+        if (c->bvhTableCap < c->bvhs.size()) {
+            if (c->bvhTable)
+                HIP_TRY(c, hipFree(c->bvhTable));
+            c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
+        }
+        HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
+        c->bvhTableDirty = false;
+    }
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    int rc = ensureBuf(c, c->blockWork, alignUp(n_work * 4));
+    if (rc != PGPU_OK)
+        return rc;
+    uint32_t* dWorkBvh = static_cast<uint32_t*>(c->blockWork.ptr);
+    HIP_TRY(c, launchLeafToBvh(work_leaf, c->top.leaves, c->top.n_leaves, dWorkBvh, uint32_t(n_work),
+                   uint32_t(std::min<size_t>((n_work + 255) / 256, size_t(c->numCUs) * 8)), stream));
+    Bvh8TraceArgs ba {};
+    ba.bvhs = c->bvhTable;
+    ba.work_ray = work_ray;
+    ba.work_bvh = dWorkBvh;
+    ba.work_tag = work_leaf;
+    ba.n_work = uint32_t(n_work);
+    ba.ox = rp[0];
+    ba.oy = rp[1];
+    ba.oz = rp[2];
+    ba.dx = rp[3];
+    ba.dy = rp[4];
+    ba.dz = rp[5];
+    ba.tnear = rp[6];
+    ba.tfar_in = kind == PGPU_CLOSEST ? hits->t : rp[7];
+    if (kind == PGPU_CLOSEST) {
+        ba.t_out = hits->t;
+        ba.obj_out = hits->obj;
+        ba.leaf_out = hits->leaf;
+        ba.u_out = hits->u;
+        ba.v_out = hits->v;
+    }
+    ba.any_out = any_hit;
+    ba.cursor = c->cursor;
+    ba.chunk = c->chunk;
+    ba.init_miss = 0;
+    ba.stats = c->stats ? c->statsDev : nullptr;
+    uint32_t deepest = 0;
+    for (const Bvh8Dev& b : c->bvhs)
+        deepest = std::max(deepest, b.depth);
+    HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+    uint32_t blocks = 1;
+    rc = planBvh8Launch(c, deepest, n_work, ba, &blocks);
+    if (rc != PGPU_OK)
+        return rc;
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
     return PGPU_OK;
 }
 }

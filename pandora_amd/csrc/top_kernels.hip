@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
             a.parked_leaf[w] = parked ? leafId : PGPU_MISS_ID;
         if (__ballot(parked) != 0) {
             const KeyGroup kg = groupByKey(leafId, parked);
-            if (parked && kg.leader == (threadIdx.x & 63u)) {
+            if (a.leaf_count && parked && kg.leader == (threadIdx.x & 63u)) {
                 if (countInLds)
                     atomicAdd(&ldsCount[2u + leafId], kg.size);
                 else
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
     __syncthreads();
     if (threadIdx.x < 2u && ldsCount[threadIdx.x] != 0u)
         atomicAdd(&a.counters[threadIdx.x], (unsigned long long)ldsCount[threadIdx.x]);
-    if (countInLds)
+    if (countInLds && a.leaf_count)
         for (uint32_t i = threadIdx.x; i < a.top.n_leaves; i += kTopBlock)
             if (ldsCount[2u + i] != 0u)
                 atomicAdd(&a.leaf_count[i], ldsCount[2u + i]);
@@ -426,6 +426,15 @@ __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void leafToBvhKernel(const uint32_t* __restrict__ workLeaf, const TopLeafDev* __restrict__ leaves, uint32_t nLeaves,
+    uint32_t* __restrict__ workBvh, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t l = workLeaf[i];
+        workBvh[i] = l < nLeaves ? leaves[l].bvh : PGPU_MISS_ID;
+    }
+}
+
 __global__ __launch_bounds__(256) void initStateKernel(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn,
     float* tState, uint32_t* obj, uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut)
 {
@@ -491,6 +500,12 @@ hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, u
     }
     hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, leafStart, leafFill, leaves,
         workRay, workBvh, workLeaf);
+    return hipGetLastError();
+}
+
+hipError_t launchLeafToBvh(const uint32_t* workLeaf, const TopLeafDev* leaves, uint32_t nLeaves, uint32_t* workBvh, uint32_t n, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(leafToBvhKernel, dim3(blocks), dim3(256), 0, stream, workLeaf, leaves, nLeaves, workBvh, n);
     return hipGetLastError();
 }
 

@@ -1,0 +1,186 @@
+"""Two-level traversal with the batching points sharded over several GPUs (BASELINE config 4).
+
+Every rank holds the top-level BVH4 and the SVDAGs (KBs..MBs) and the bottom-level BVH8s of the batching points
+it owns. Rays live on their home rank. One round:
+
+  home:   top-level episode for the active rays  -> (ray, batching point) for every ray that parked
+  home:   records {ray 8 x f32 with tfar = current t, home slot} sorted by owner(batching point)
+  all-to-all (RCCL over xGMI; counts first, then the records)
+  owner:  bottom-level traversal of the received rays through the named batching points
+  all-to-all back: {t, obj, u, v}
+  home:   merge closer hits, resume the parked rays in the next round
+
+until no rank has a parked ray. This replaces the reference's per-leaf MPMC queues + disk cache
+(offline_batching_acceleration_structure.h:158-260, task_graph.cpp:19-56): a leaf's "queue" is whatever the
+exchange delivers to its owner in a round. Visit order per ray is the top-level traversal's, exactly as on
+one GPU, so results are identical to pgpu_trace.
+
+The loop is written against a small engine interface so that the routing logic can be exercised on CPU ranks
+(gloo) with a CPU engine in tests; the product engine is GpuEngine (the C ABI).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+MISS = 0xFFFFFFFF
+
+
+def assign_leaves(weights, world: int) -> np.ndarray:
+    """Owner rank per batching point: greedy longest-processing-time balance of `weights` (bytes or expected
+    ray load). Deterministic, so every rank computes the same table."""
+    w = np.asarray(weights, np.float64)
+    owner = np.zeros(w.size, np.int64)
+    load = np.zeros(world, np.float64)
+    for i in np.argsort(-w, kind="stable"):
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += w[i]
+    return owner
+
+
+def _world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def _all_to_all_rows(rows: torch.Tensor, send_counts: torch.Tensor, staging_cpu: bool):
+    """rows [k, c] grouped by destination rank, send_counts [world] -> (received rows, recv_counts)."""
+    rank, world = _world()
+    if world == 1:
+        return rows, send_counts.clone()
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = [int(x) for x in send_counts.tolist()], [int(x) for x in recv_counts.tolist()]
+    src = rows.cpu() if staging_cpu else rows
+    out = torch.empty((sum(rc), rows.shape[1]), dtype=rows.dtype, device=src.device)
+    dist.all_to_all_single(out, src.contiguous(), output_split_sizes=rc, input_split_sizes=sc)
+    return (out.to(rows.device) if staging_cpu else out), recv_counts
+
+
+class GpuEngine:
+    """The product engine: pandora_hip through the C ABI, device tensors."""
+
+    def __init__(self, ctx, device: torch.device, tri_mode: int = capi.TRI_MT):
+        self.ctx, self.device, self.tri_mode = ctx, device, tri_mode
+        # The library's kernels and torch's own (sorting, gathering the records) must run on ONE stream so that they
+        # are ordered: a side stream of torch's, handed to every library call. (Stream 0 would make the library fall
+        # back to its private stream, which torch knows nothing about.)
+        self.stream = torch.cuda.Stream(device)
+
+    def stream_context(self):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self.stream)
+
+    def init_state(self, rays, kind):
+        n = rays.shape[1]
+        z = lambda dt: torch.empty(n, dtype=dt, device=self.device)
+        st = {"node": z(torch.int32), "stack": z(torch.int64), "visits": torch.zeros(n, dtype=torch.int32, device=self.device)}
+        if kind == capi.CLOSEST:
+            st.update(t=z(torch.float32), obj=z(torch.int32), leaf=z(torch.int32), u=z(torch.float32), v=z(torch.float32))
+            self.ctx.ray_state_init(rays[7], st["node"], st["stack"], st, stream=self.stream.cuda_stream)
+        else:
+            st["hit"] = z(torch.int32)
+            self.ctx.ray_state_init(None, st["node"], st["stack"], None, st["hit"], stream=self.stream.cuda_stream)
+        return st
+
+    def top_episode(self, kind, rays, active, st):
+        n_active = int(active.shape[0])
+        parked = torch.empty(n_active, dtype=torch.int32, device=self.device)
+        self.ctx.top_episode(kind, rays, active, n_active, st["node"], st["stack"], st.get("t"), st["visits"], st.get("hit"), parked,
+                             stream=self.stream.cuda_stream)
+        return parked
+
+    def trace_leaves(self, kind, rays, work_leaf):
+        """rays [8, k] (tfar = current t), work_leaf [k] -> closest: (t, obj, u, v) with obj = MISS where nothing closer; any: hit flags."""
+        k = rays.shape[1]
+        work_ray = torch.arange(k, dtype=torch.int32, device=self.device)
+        order = torch.argsort(work_leaf.to(torch.int64), stable=True).to(torch.int32)  # rays of one leaf adjacent
+        wl = work_leaf[order.long()].contiguous()
+        wr = work_ray[order.long()].contiguous()
+        if kind == capi.CLOSEST:
+            hits = {"t": rays[7].clone(), "obj": torch.full((k,), -1, dtype=torch.int32, device=self.device),
+                    "leaf": torch.zeros(k, dtype=torch.int32, device=self.device),
+                    "u": torch.zeros(k, dtype=torch.float32, device=self.device), "v": torch.zeros(k, dtype=torch.float32, device=self.device)}
+            self.ctx.trace_leaves(kind, self.tri_mode, rays, wr, wl, k, hits, stream=self.stream.cuda_stream)
+            return hits["t"], hits["obj"], hits["u"], hits["v"]
+        hit = torch.zeros(k, dtype=torch.int32, device=self.device)
+        self.ctx.trace_leaves(kind, self.tri_mode, rays, wr, wl, k, None, hit, stream=self.stream.cuda_stream)
+        return hit
+
+    def finish(self):
+        self.ctx.sync(self.stream.cuda_stream)
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+
+def trace_sharded(engine, rays: torch.Tensor, owner_of_leaf, kind: int = capi.CLOSEST, staging_cpu: bool | None = None):
+    """Traces this rank's rays [8, n] through the sharded scene. owner_of_leaf: int array over leaf slots.
+    Returns (state dict: t/obj/leaf/u/v/visits or hit/visits, info dict: rounds, leaf_visits, routed)."""
+    if hasattr(engine, "stream_context"):
+        with engine.stream_context():
+            return _trace_sharded(engine, rays, owner_of_leaf, kind, staging_cpu)
+    return _trace_sharded(engine, rays, owner_of_leaf, kind, staging_cpu)
+
+
+def _trace_sharded(engine, rays: torch.Tensor, owner_of_leaf, kind: int = capi.CLOSEST, staging_cpu: bool | None = None):
+    rank, world = _world()
+    dev = rays.device
+    if staging_cpu is None:
+        staging_cpu = world > 1 and dist.get_backend() != "nccl" and dev.type != "cpu"
+    owner = torch.as_tensor(np.asarray(owner_of_leaf, np.int64), device=dev)
+    n = rays.shape[1]
+    st = engine.init_state(rays, kind)
+    active = torch.arange(n, dtype=torch.int32, device=dev)
+    rounds = leaf_visits = routed = 0
+    while True:
+        parked = engine.top_episode(kind, rays, active, st) if active.numel() else torch.empty(0, dtype=torch.int32, device=dev)
+        keep = parked != -1  # int32 view of MISS
+        slots = active[keep].long()      # home ray ids that parked
+        leaves = parked[keep].long().clamp_(0, owner.numel() - 1)  # (a corrupt id must not become a wild gather)
+        total = torch.tensor([slots.numel()], dtype=torch.int64, device=("cpu" if staging_cpu or dev.type == "cpu" else dev))
+        if world > 1:
+            dist.all_reduce(total)
+        if int(total.item()) == 0:
+            break
+        rounds += 1
+        leaf_visits += int(slots.numel())
+        dest = owner[leaves]
+        order = torch.argsort(dest, stable=True)
+        slots, leaves, dest = slots[order], leaves[order], dest[order]
+        send_counts = torch.bincount(dest, minlength=world).to(torch.int64)
+        routed += int(slots.numel() - int(send_counts[rank]))
+        # record = the ray with tfar replaced by its current t (closest hit), then the leaf (bit pattern in a float lane)
+        rec = rays[:, slots].t().contiguous()                      # [k, 8]
+        if kind == capi.CLOSEST:
+            rec[:, 7] = st["t"][slots]
+        rec = torch.cat([rec, leaves.to(torch.int32).view(-1, 1).view(torch.float32)], dim=1)  # [k, 9]
+        cc = send_counts.cpu() if (staging_cpu or dev.type == "cpu") else send_counts
+        got, recv_counts = _all_to_all_rows(rec, cc, staging_cpu)
+        k = got.shape[0]
+        if k:
+            r_in = got[:, :8].t().contiguous()
+            wl = got[:, 8].contiguous().view(torch.int32)
+            if kind == capi.CLOSEST:
+                t, obj, u, v = engine.trace_leaves(kind, r_in, wl)
+                res = torch.stack([t, obj.view(torch.float32), u, v], dim=1)
+            else:
+                res = engine.trace_leaves(kind, r_in, wl).view(torch.float32).view(-1, 1)
+        else:
+            res = torch.empty((0, 4 if kind == capi.CLOSEST else 1), dtype=torch.float32, device=dev)
+        back, _ = _all_to_all_rows(res, recv_counts, staging_cpu)  # rows return in the order they were sent
+        if kind == capi.CLOSEST:
+            hit = back[:, 1].contiguous().view(torch.int32) != -1
+            hs = slots[hit]
+            st["t"][hs] = back[hit, 0]
+            st["obj"][hs] = back[hit, 1].contiguous().view(torch.int32)
+            st["leaf"][hs] = leaves[hit].to(torch.int32)
+            st["u"][hs] = back[hit, 2]
+            st["v"][hs] = back[hit, 3]
+        else:
+            hit = back[:, 0].contiguous().view(torch.int32) != 0
+            st["hit"][slots[hit]] = 1
+        active = slots.to(torch.int32).contiguous()
+    engine.finish()
+    return st, {"rounds": rounds, "leaf_visits": leaf_visits, "routed": routed}

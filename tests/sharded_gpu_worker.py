@@ -1,0 +1,42 @@
+"""One rank of the 2-process GPU test of the leaf-sharded loop (both ranks share GPU 0; records travel over gloo
+through host memory). Started by tests/test_gpu_sharded.py with RANK / WORLD_SIZE / MASTER_* set."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import pandora_amd as pa  # noqa: E402
+from pandora_amd import sharded  # noqa: E402
+
+
+def main():
+    out_dir, kind = sys.argv[1], int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        mesh = pa.scenes.g_small()
+        tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=32)
+        owner_by_input = sharded.assign_leaves([b.n_nodes for b in tl.bvhs], world)
+        owner = owner_by_input[np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
+        ctx = pa.accel.Context(0)
+        tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
+        rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
+        eng = sharded.GpuEngine(ctx, dev)
+        st, info = sharded.trace_sharded(eng, torch.from_numpy(np.ascontiguousarray(rays)).to(dev), owner, kind)
+        cnt = ctx.counters()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), routed=info["routed"], rounds=info["rounds"], leaf_visits=info["leaf_visits"],
+                 svdag_tests=cnt["svdag_tests"], svdag_culled=cnt["svdag_culled"],
+                 **{k: v.cpu().numpy() for k, v in st.items() if k not in ("node", "stack")})
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""GPU parity of the sharded-loop building blocks (pgpu_ray_state_init / pgpu_top_episode / pgpu_trace_leaves):
+driven by pandora_amd.sharded they must reproduce pgpu_trace bit for bit -- in one process, and with the batching
+points split over two processes that exchange ray records (gloo through host memory; both share the one GPU)."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import pandora_amd as pa
+from pandora_amd import sharded
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _bits(a):
+    return np.asarray(a).view(np.uint32)
+
+
+def _rays(mesh):
+    prim = pa.scenes.primary_rays((0, 1, 3.2), (0, 1, 0), (0, 1, 0), 50, 64, 64)
+    rnd = pa.scenes.random_rays((-3, -1, -3), (3, 3, 3), 4000, seed=5)
+    far = pa.scenes.random_rays((-300, -300, -300), (300, 300, 300), 3000, seed=6, toward=((-1, 0, -1), (1, 2, 1)))
+    return np.ascontiguousarray(np.concatenate([prim, rnd, far], axis=1))
+
+
+@pytest.fixture(scope="module")
+def scene():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    mesh = pa.scenes.g_small()
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=32)
+    ctx = pa.accel.Context(0)
+    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+    yield ctx, mesh, tl
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
+def test_single_process_blocks_equal_pgpu_trace(scene, kind):
+    import torch
+    ctx, mesh, tl = scene
+    rays = _rays(mesh)
+    want, wcnt = ctx.trace(rays, kind=kind)
+    dev = torch.device("cuda", 0)
+    before = ctx.counters()
+    st, info = sharded.trace_sharded(sharded.GpuEngine(ctx, dev), torch.from_numpy(rays).to(dev), np.zeros(tl.n_leaves, np.int64), kind)
+    after = ctx.counters()
+    keys = ("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")
+    for k in keys:
+        assert np.array_equal(_bits(st[k].cpu().numpy()), _bits(want[k])), k
+    assert info["rounds"] == wcnt["rounds"] and info["leaf_visits"] == wcnt["leaf_visits"]
+    assert after["svdag_tests"] - before["svdag_tests"] == wcnt["svdag_tests"]
+    assert after["svdag_culled"] - before["svdag_culled"] == wcnt["svdag_culled"]
+
+
+def test_trace_rejects_non_resident_leaves():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    mesh = pa.scenes.g_small()
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64)
+    ctx = pa.accel.Context(0)
+    resident = np.zeros(tl.n_leaves, bool)
+    resident[::2] = True
+    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=resident)
+    with pytest.raises(pa.capi.PandoraError) as e:
+        ctx.trace(np.ascontiguousarray(_rays(mesh)[:, :64]))
+    assert e.value.code == pa.capi.ERR_NO_SCENE
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
+def test_two_processes_sharded_leaves(scene, kind):
+    ctx, mesh, tl = scene
+    rays = _rays(mesh)
+    want, wcnt = ctx.trace(rays, kind=kind)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "rays.npy"), rays)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(kind)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+        parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(2)]
+    assert sum(int(p["routed"]) for p in parts) > 0
+    keys = ("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")
+    for r, p in enumerate(parts):
+        for k in keys:
+            assert np.array_equal(_bits(p[k]), _bits(want[k])[r::2]), f"rank {r}: {k}"
+    assert sum(int(p["leaf_visits"]) for p in parts) == wcnt["leaf_visits"]
+    assert sum(int(p["svdag_tests"]) for p in parts) == wcnt["svdag_tests"]
+    assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
