@@ -48,3 +48,14 @@ diff = pa.scenes.diffuse_bounce_rays(mesh, prim, t, primid)
 dd = torch.from_numpy(diff).cuda()
 run(dd, pa.capi.CLOSEST, "diffuse closest")
 run(dd, pa.capi.ANY, "diffuse any")
+# the same loop through the sharded-loop building blocks (one rank: no exchange, torch sorts/gathers per round)
+from pandora_amd import sharded
+eng = sharded.GpuEngine(ctx, torch.device("cuda", 0))
+owner = np.zeros(tl.n_leaves, np.int64)
+for label, rays_d, kind in (("sharded-loop primary closest", d, pa.capi.CLOSEST), ("sharded-loop diffuse closest", dd, pa.capi.CLOSEST)):
+    best = 1e30
+    for it in range(3):
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        st, info = sharded.trace_sharded(eng, rays_d, owner, kind)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t1)
+    print("%s: wall %.3f ms (%.1f Mrays/s), rounds %d" % (label, best * 1e3, rays_d.shape[1] / best / 1e6, info["rounds"]), flush=True)
