@@ -131,6 +131,17 @@ typedef struct {
 } pgpu_leaf;
 int pgpu_upload_top_bvh4(pgpu_ctx*, const void* nodes112, size_t n_nodes, uint32_t root, const pgpu_leaf* leaves, size_t n_leaves);
 
+/* ------------------------------------------------------------------ on-disk BVH8 (host only)
+ * The flatbuffer the reference writes for a cached bottom-level BVH (pandora/flatbuffers/wive_bvh8.fbs +
+ * contiguous_allocator.fbs; WiVeBVH8::serialize, wive_bvh8_impl.h:37-49; read back by GetWiVeBVH8,
+ * offline_bvh_cache.cpp:138-143). serialize returns a malloc'ed buffer (pgpu_bytes_free); deserialize returns
+ * pointers INTO `bytes` (4-byte aligned; pgpu_upload_bvh8 copies), every offset bounds-checked. */
+int pgpu_bvh8_serialize(const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_leaf_indices, uint32_t root_handle,
+    uint64_t num_leaf_objects, void** out_bytes, size_t* out_size);
+int pgpu_bvh8_deserialize(const void* bytes, size_t size, const void** nodes256, size_t* n_nodes, const uint32_t** leaf_indices,
+    size_t* n_leaf_indices, uint32_t* root_handle, uint64_t* num_leaf_objects);
+void pgpu_bytes_free(void* bytes);
+
 /* ------------------------------------------------------------------ tracing
  * SoA ray batch: Ray{origin, direction, tnear, tfar} of graphics_core/ray.h:14-40. */
 typedef struct {

@@ -70,6 +70,53 @@ class HostBvh4:
     depth: int
 
 
+def bvh8_to_bytes(bvh: HostBvh8) -> bytes:
+    """The reference's on-disk flatbuffer of a bottom-level BVH (wive_bvh8.fbs). The leaf-object table is not part of it
+    (the reference dumps raw pointers there, offline_bvh_cache.cpp:125-129); save `prim_ids` next to it."""
+    L = capi.lib()
+    out, n = C.c_void_p(), C.c_size_t()
+    nodes = np.ascontiguousarray(bvh.nodes)
+    idx = np.ascontiguousarray(bvh.leaf_idx, np.uint32)
+    _check(L.pgpu_bvh8_serialize(nodes.ctypes.data, bvh.n_nodes, idx.ctypes.data, idx.size, bvh.root, bvh.prim_ids.size, C.byref(out), C.byref(n)),
+           what="pgpu_bvh8_serialize failed")
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        L.pgpu_bytes_free(out)
+
+
+def bvh8_from_bytes(data: bytes, prim_ids: np.ndarray) -> HostBvh8:
+    L = capi.lib()
+    buf = np.frombuffer(data, np.uint8)
+    nodes, n_nodes, idx, n_idx = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+    root, n_obj = C.c_uint32(), C.c_uint64()
+    _check(L.pgpu_bvh8_deserialize(buf.ctypes.data, buf.size, C.byref(nodes), C.byref(n_nodes), C.byref(idx), C.byref(n_idx), C.byref(root), C.byref(n_obj)),
+           what="pgpu_bvh8_deserialize: not a WiVeBVH8 flatbuffer")
+    prim_ids = np.ascontiguousarray(prim_ids, np.uint32)
+    if int(n_obj.value) != prim_ids.size:
+        raise PandoraError(capi.ERR_INVALID, "Number of leaf objects does not match that of the serialized BVH")  # wive_bvh8_impl.h:31
+    node_arr = np.frombuffer(data, np.uint8, count=n_nodes.value * 256, offset=nodes.value - buf.ctypes.data).view(np.float32).reshape(-1, 64).copy() if n_nodes.value else np.zeros((0, 64), np.float32)
+    idx_arr = np.frombuffer(data, np.uint32, count=n_idx.value, offset=idx.value - buf.ctypes.data).copy() if n_idx.value else np.zeros(0, np.uint32)
+    return HostBvh8(node_arr, idx_arr, int(root.value), host_bvh8_depth(node_arr, int(root.value)), prim_ids)
+
+
+def host_bvh8_depth(nodes: np.ndarray, root: int) -> int:
+    """Nested inner nodes below `root` (iterative; handles as wive_bvh8_impl.h:333-382)."""
+    u = nodes.view(np.uint32).reshape(-1, 64)
+    depth, todo = 0, [(root, 1)]
+    if (root >> 29) != 2:
+        return 0
+    while todo:
+        h, d = todo.pop()
+        if (h & 0x1FFFFFFF) >= u.shape[0] or d > 64:
+            raise PandoraError(capi.ERR_INVALID, "BVH8 node handle out of range or tree deeper than 64 (damaged file?)")
+        depth = max(depth, d)
+        for c in u[h & 0x1FFFFFFF, 48:56]:
+            if (int(c) >> 29) == 2:
+                todo.append((int(c), d + 1))
+    return depth
+
+
 def build_top_bvh4(leaf_bounds: np.ndarray) -> HostBvh4:
     L = capi.lib()
     b = np.ascontiguousarray(leaf_bounds, np.float32).reshape(-1, 6)

@@ -72,6 +72,10 @@ SYMBOLS = {
     "pgpu_host_svdags_free": (None, [C.c_void_p]),
     "pgpu_svdag_expand": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(SvdagDesc), C.c_void_p]),
     "pgpu_voxelize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pgpu_bvh8_serialize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "pgpu_bvh8_deserialize": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "pgpu_bytes_free": (None, [C.c_void_p]),
     "pgpu_init": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "pgpu_shutdown": (None, [C.c_void_p]),
     "pgpu_last_error": (C.c_char_p, [C.c_void_p]),
