@@ -212,86 +212,86 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
         uint32_t leafId = 0;
         // a shadow ray already occluded in its last leaf is done (offline_batching...h:246-247)
         if (live && !(ANY && a.any_out[ray] != 0u)) {
-        const float ox = a.ox[ray], oy = a.oy[ray], oz = a.oz[ray];
-        const float dx = a.dx[ray], dy = a.dy[ray], dz = a.dz[ray];
-        const float tnear = a.tnear[ray];
-        const float tfar = ANY ? a.tfar_in[ray] : a.tfar_state[ray]; // simdRay is rebuilt from the ray at every resume (:243-254)
-        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // :241
-        uint32_t node = a.node[ray];
-        uint64_t stack = a.stack[ray];
-        for (;;) {
-            const float* nf = reinterpret_cast<const float*>(nodeBase + size_t(node) * kTopNodeBytes);
-            const uint32_t* nu = reinterpret_cast<const uint32_t*>(nf);
-            const uint32_t bits = nu[27];
-            const uint32_t valid = bits & 0xFu, leafMask = (bits >> 4) & 0xFu;
-            const int bitPos = 4 * int((bits >> 8) & 0xFFu);
-            const uint64_t interest = (stack >> bitPos) & 0xFull;
-            bool descended = false;
-            if (interest != 0) {
-                float tmin[4];
-                uint32_t hitMask = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float tx1 = (nf[0 + i] - ox) * ix, tx2 = (nf[12 + i] - ox) * ix;
-                    const float ty1 = (nf[4 + i] - oy) * iy, ty2 = (nf[16 + i] - oy) * iy;
-                    const float tz1 = (nf[8 + i] - oz) * iz, tz2 = (nf[20 + i] - oz) * iz;
-                    const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
-                    const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
-                    tmin[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin)));
-                    const float tmax = min86(tfar, min86(txMax, min86(tyMax, tzMax)));
-                    hitMask |= uint32_t(tmin[i] <= tmax) << i;
-                }
-                const uint32_t toVisit = hitMask & uint32_t(interest) & valid;
-                if (toVisit != 0) {
-                    uint32_t child;
-                    if (ANY) {
-                        child = (toVisit & 1u) ? 0u : ((toVisit & 2u) ? 1u : ((toVisit & 4u) ? 2u : 3u)); // bitScan4
-                    } else {
-                        float masked[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            masked[i] = (toVisit >> i & 1u) ? tmin[i] : 3.4028234663852886e38f;
-                        child = hminIndex4(masked);
+            const float ox = a.ox[ray], oy = a.oy[ray], oz = a.oz[ray];
+            const float dx = a.dx[ray], dy = a.dy[ray], dz = a.dz[ray];
+            const float tnear = a.tnear[ray];
+            const float tfar = ANY ? a.tfar_in[ray] : a.tfar_state[ray]; // simdRay is rebuilt from the ray at every resume (:243-254)
+            const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // :241
+            uint32_t node = a.node[ray];
+            uint64_t stack = a.stack[ray];
+            for (;;) {
+                const float* nf = reinterpret_cast<const float*>(nodeBase + size_t(node) * kTopNodeBytes);
+                const uint32_t* nu = reinterpret_cast<const uint32_t*>(nf);
+                const uint32_t bits = nu[27];
+                const uint32_t valid = bits & 0xFu, leafMask = (bits >> 4) & 0xFu;
+                const int bitPos = 4 * int((bits >> 8) & 0xFFu);
+                const uint64_t interest = (stack >> bitPos) & 0xFull;
+                bool descended = false;
+                if (interest != 0) {
+                    float tmin[4];
+                    uint32_t hitMask = 0;
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float tx1 = (nf[0 + i] - ox) * ix, tx2 = (nf[12 + i] - ox) * ix;
+                        const float ty1 = (nf[4 + i] - oy) * iy, ty2 = (nf[16 + i] - oy) * iy;
+                        const float tz1 = (nf[8 + i] - oz) * iz, tz2 = (nf[20 + i] - oz) * iz;
+                        const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
+                        const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
+                        tmin[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin)));
+                        const float tmax = min86(tfar, min86(txMax, min86(tyMax, tzMax)));
+                        hitMask |= uint32_t(tmin[i] <= tmax) << i;
                     }
-                    uint64_t rest = uint64_t(toVisit) ^ (1ull << child);
-                    stack = stack ^ (interest << bitPos);
-                    stack = stack | (rest << bitPos);
-                    if ((valid & ~leafMask) >> child & 1u) {
-                        node = nu[24] + __popc((valid & ~leafMask) & ((1u << child) - 1u));
-                    } else {
-                        const uint32_t leaf = nu[25] + __popc((valid & leafMask) & ((1u << child) - 1u));
-                        const TopLeafDev lf = a.top.leaves[leaf];
-                        bool culled = false;
-                        if (lf.svdag != PGPU_MISS_ID) {
-                            ++nTests;
-                            const SvdagDev dag = a.top.dags[lf.svdag];
-                            if (!svdagHit(a.top.dagWords, dag, ox, oy, oz, dx, dy, dz, dagStack + threadIdx.x, kTopBlock)) {
-                                ++nCulled;
-                                culled = true;
+                    const uint32_t toVisit = hitMask & uint32_t(interest) & valid;
+                    if (toVisit != 0) {
+                        uint32_t child;
+                        if (ANY) {
+                            child = (toVisit & 1u) ? 0u : ((toVisit & 2u) ? 1u : ((toVisit & 4u) ? 2u : 3u)); // bitScan4
+                        } else {
+                            float masked[4];
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                masked[i] = (toVisit >> i & 1u) ? tmin[i] : 3.4028234663852886e38f;
+                            child = hminIndex4(masked);
+                        }
+                        uint64_t rest = uint64_t(toVisit) ^ (1ull << child);
+                        stack = stack ^ (interest << bitPos);
+                        stack = stack | (rest << bitPos);
+                        if ((valid & ~leafMask) >> child & 1u) {
+                            node = nu[24] + __popc((valid & ~leafMask) & ((1u << child) - 1u));
+                        } else {
+                            const uint32_t leaf = nu[25] + __popc((valid & leafMask) & ((1u << child) - 1u));
+                            const TopLeafDev lf = a.top.leaves[leaf];
+                            bool culled = false;
+                            if (lf.svdag != PGPU_MISS_ID) {
+                                ++nTests;
+                                const SvdagDev dag = a.top.dags[lf.svdag];
+                                if (!svdagHit(a.top.dagWords, dag, ox, oy, oz, dx, dy, dz, dagStack + threadIdx.x, kTopBlock)) {
+                                    ++nCulled;
+                                    culled = true;
+                                }
+                            }
+                            if (!culled) {
+                                parked = true;
+                                leafId = leaf;
+                                break;
                             }
                         }
-                        if (!culled) {
-                            parked = true;
-                            leafId = leaf;
-                            break;
-                        }
+                        descended = true;
                     }
-                    descended = true;
                 }
+                if (descended)
+                    continue;
+                stack = stack | (0xFFFFFFFFFFFFFFFFull << bitPos);
+                if (stack == 0xFFFFFFFFFFFFFFFFull)
+                    break;
+                node = nu[26];
             }
-            if (descended)
-                continue;
-            stack = stack | (0xFFFFFFFFFFFFFFFFull << bitPos);
-            if (stack == 0xFFFFFFFFFFFFFFFFull)
-                break;
-            node = nu[26];
-        }
-        if (parked) {
-            a.node[ray] = node;
-            a.stack[ray] = stack;
-            if (a.visits)
-                a.visits[ray] += 1u; // Ray::numTopLevelIntersections (:283)
-        }
+            if (parked) {
+                a.node[ray] = node;
+                a.stack[ray] = stack;
+                if (a.visits)
+                    a.visits[ray] += 1u; // Ray::numTopLevelIntersections (:283)
+            }
         }
         // park: the round's list keeps one entry per work item (the batching point, or none), one count per point
         if (live)

@@ -104,3 +104,28 @@ def test_two_level_equals_single_level_at_scale(city):
         assert np.array_equal(_bits(gs[k]), _bits(want[k])), k
     for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
         assert cs[k] == want["counters"][k], k
+
+
+def test_many_batching_points_take_the_global_memory_paths():
+    """6000 batching points: the top-level nodes (346 KB) do not fit LDS and the per-point counters exceed the LDS
+    histogram, so the kernels read nodes from HBM and count / bin with wave-aggregated global atomics."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    mesh = pa.scenes.g_city(1, 40000)
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 12)
+    assert tl.n_leaves > 4096 and tl.top.nodes.shape[0] * 112 > 40 * 1024
+    ctx = pa.accel.Context(0)
+    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+    prim = pa.scenes.primary_rays((2.0, 14.0, 2.0), (12.0, 0.0, 12.0), (0, 1, 0), 60, 160, 160)
+    rnd = pa.scenes.random_rays((0, 0, 0), (20, 12, 20), 8000, seed=12)
+    rays = np.ascontiguousarray(np.concatenate([prim, rnd], axis=1))
+    scene = ob.scene_from_two_level(tl, mesh)
+    for kind in (pa.capi.CLOSEST, pa.capi.ANY):
+        got, cnt = ctx.trace(rays, kind=kind)
+        want = scene.trace(rays, any_hit=(kind == pa.capi.ANY), lanes=3, threads=8)
+        keys = ("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")
+        for k in keys:
+            assert np.array_equal(_bits(got[k]), _bits(want[k])), k
+        assert cnt["leaf_visits"] == want["counters"]["leaf_visits"]
+    ctx.close()
