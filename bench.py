@@ -36,6 +36,8 @@ def main() -> None:
     ap.add_argument("--side", type=int, default=4096, help="primary-ray image side; batch ~ side^2 diffuse rays")
     ap.add_argument("--tris", type=int, default=262144)
     ap.add_argument("--kind", choices=["closest", "any"], default="closest")
+    ap.add_argument("--tri", choices=["moller-trumbore", "watertight"], default="moller-trumbore",
+                    help="leaf test: the branch the reference compiles (triangle_intersect.cpp:425-462) or its watertight variant (:340-423)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 21)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -73,10 +75,11 @@ def main() -> None:
     n = int(rays.shape[1])
     d_rays = torch.from_numpy(rays).to(dev)
     kind = pa.capi.CLOSEST if args.kind == "closest" else pa.capi.ANY
-    out = ctx.trace_bvh8(bvh, d_rays, kind=kind, stream=stream)  # allocates the result arrays once
+    tri_mode = pa.capi.TRI_MT if args.tri == "moller-trumbore" else pa.capi.TRI_WATERTIGHT
+    out = ctx.trace_bvh8(bvh, d_rays, kind=kind, tri_mode=tri_mode, stream=stream)  # allocates the result arrays once
 
     def step():
-        ctx.trace_bvh8(bvh, d_rays, kind=kind, out=out, stream=stream)
+        ctx.trace_bvh8(bvh, d_rays, kind=kind, tri_mode=tri_mode, out=out, stream=stream)
 
     for _ in range(args.warmup):
         step()
@@ -124,7 +127,7 @@ def main() -> None:
             orc = ob.OracleBvh8.from_host(hb, mesh)
             sub = np.ascontiguousarray(rays[:, :sample])
             c0 = time.perf_counter()
-            want = orc.trace(sub, any_hit=(args.kind == "any"), threads=threads)
+            want = orc.trace(sub, any_hit=(args.kind == "any"), tri_mode=tri_mode, threads=threads)
             c1 = time.perf_counter()
             if args.kind == "closest":
                 same = all(np.array_equal(out[k][:sample].cpu().numpy().view(np.uint32), want[k].view(np.uint32)) for k in ("t", "obj", "u", "v"))
@@ -138,7 +141,7 @@ def main() -> None:
         # (tools/pmc_passes.sh), which cannot run inside the timed process; the committed summary is quoted.
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.kind == "closest" and os.path.exists(tpath):
+        if args.kind == "closest" and args.tri == "moller-trumbore" and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("rays_per_launch") == n:
@@ -149,7 +152,7 @@ def main() -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, args.kind),
                        "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
-                       "triangle_test": "moller-trumbore", "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world},
+                       "triangle_test": args.tri, "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "scene_bytes": scene_bytes},

@@ -5,7 +5,7 @@ import numpy as np, torch
 import pandora_amd as pa
 
 n_side = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-mesh = pa.scenes.g_atrium()
+mesh = pa.scenes.g_atrium(int(sys.argv[2]) if len(sys.argv) > 2 else 262144)
 t0 = time.time(); hb = pa.accel.build_bvh8(mesh.pos, mesh.idx); print("build %.2fs nodes %d depth %d tris %d" % (time.time() - t0, hb.n_nodes, hb.depth, mesh.n_tris), flush=True)
 ctx = pa.accel.Context(0)
 bvh = ctx.upload_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
