@@ -120,6 +120,16 @@ typedef struct {
 int pgpu_upload_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
 
+/* Leaves streamed from host memory (BASELINE config 5; CachedBVH::doMakeResident / doEvict, offline_bvh_cache.cpp:127-148):
+ * pgpu_stage_bvh8 takes the same arguments as pgpu_upload_bvh8 but keeps the device image in pinned host memory; the
+ * two-level loop copies it into an HBM cache slot (hipMemcpyAsync on a copy stream, least recently used slot evicted)
+ * when rays are parked at its batching point. pgpu_set_leaf_cache sets the HBM budget of that cache in bytes
+ * (0 = room for every staged BVH); it must hold at least one BVH. Staged ids share the id space of uploaded ones but
+ * are valid only as pgpu_leaf.bvh_id for pgpu_trace. */
+int pgpu_stage_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_leaf_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
+int pgpu_set_leaf_cache(pgpu_ctx*, size_t bytes);
+
 /* Shared SVDAG array + one descriptor per DAG (SparseVoxelDAG members, sparse_voxel_dag.h:70-78). */
 int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags);
 
@@ -162,6 +172,7 @@ typedef struct {
     uint64_t leaf_visits;               /* rays parked at batching points, summed */
     uint64_t rounds;                    /* wavefront rounds the two-level loop needed */
     uint64_t inner_visits, leaf_pops, tri_tests; /* filled only when stats are enabled */
+    uint64_t leaf_loads, streamed_bytes; /* staged BVHs copied into the HBM leaf cache by the last pgpu_trace */
     uint64_t wave_steps, leaf_passes, refill_passes; /* kernel-loop diagnostics (stats enabled): wavefront iterations,
                                                        * those that ran the triangle code, those that fetched new rays */
 } pgpu_counters;

@@ -238,6 +238,20 @@ class Context:
                                         objs.ctypes.data, objs.shape[0], C.byref(out)), self._h)
         return int(out.value)
 
+    def stage_bvh8(self, bvh: HostBvh8, mesh_id: int) -> int:
+        """Like upload_bvh8, but the BVH stays in pinned host memory and is streamed into the HBM leaf cache on demand."""
+        objs = np.empty((bvh.prim_ids.size, 2), np.uint32)
+        objs[:, 0] = mesh_id
+        objs[:, 1] = bvh.prim_ids
+        nodes = np.ascontiguousarray(bvh.nodes)
+        out = C.c_uint32()
+        _check(self._L.pgpu_stage_bvh8(self._h, nodes.ctypes.data, bvh.n_nodes, bvh.leaf_idx.ctypes.data, bvh.leaf_idx.size, bvh.root,
+                                       objs.ctypes.data, objs.shape[0], C.byref(out)), self._h)
+        return int(out.value)
+
+    def set_leaf_cache(self, n_bytes: int):
+        _check(self._L.pgpu_set_leaf_cache(self._h, int(n_bytes)), self._h)
+
     def upload_svdags(self, dags: HostSvdags):
         descs = np.ascontiguousarray(dags.descs)
         _check(self._L.pgpu_upload_svdags(self._h, dags.words.ctypes.data, dags.words.size, descs.ctypes.data, descs.size), self._h)
@@ -361,7 +375,7 @@ class TwoLevelScene:
     def n_leaves(self) -> int:
         return len(self.groups)
 
-    def upload(self, ctx: "Context", mesh_id: int, resident=None):
+    def upload(self, ctx: "Context", mesh_id: int, resident=None, streamed: bool = False):
         """Uploads BVHs, SVDAGs and the top level. Returns bvh ids in final leaf-slot order.
 
         resident: optional bool array over leaf slots -- only those batching points' bottom-level BVHs are
@@ -369,7 +383,8 @@ class TwoLevelScene:
         SVDAGs are small and always uploaded whole."""
         slot_of = np.empty(self.n_leaves, np.int64)
         slot_of[np.asarray(self.top.leaf_order, np.int64)] = np.arange(self.n_leaves)
-        ids = [ctx.upload_bvh8(b, mesh_id) if (resident is None or bool(resident[slot_of[i]])) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
+        put = ctx.stage_bvh8 if streamed else ctx.upload_bvh8  # streamed: leaves live in pinned host memory (config 5)
+        ids = [put(b, mesh_id) if (resident is None or bool(resident[slot_of[i]])) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
         if self.dags is not None:
             ctx.upload_svdags(self.dags)
         leaves = np.empty((self.n_leaves, 2), np.uint32)

@@ -35,7 +35,7 @@ class Hits(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "rounds", "inner_visits", "leaf_pops", "tri_tests", "wave_steps", "leaf_passes", "refill_passes")]
+    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "rounds", "inner_visits", "leaf_pops", "tri_tests", "leaf_loads", "streamed_bytes", "wave_steps", "leaf_passes", "refill_passes")]
 
 
 class LeafObj(C.Structure):
@@ -82,6 +82,8 @@ SYMBOLS = {
     "pgpu_version": (C.c_char_p, []),
     "pgpu_upload_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "pgpu_upload_bvh8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pgpu_stage_bvh8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pgpu_set_leaf_cache": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pgpu_upload_svdags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "pgpu_upload_top_bvh4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),
     "pgpu_trace_bvh8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.c_int, C.POINTER(Hits), C.c_void_p, C.c_void_p]),

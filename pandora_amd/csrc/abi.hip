@@ -227,6 +227,18 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipFree(c->statsDev);
     if (c->topCounters)
         (void)hipFree(c->topCounters);
+    for (StagedBvh& s : c->staged)
+        if (s.host)
+            (void)hipHostFree(s.host);
+    for (CacheSlot& s : c->slots)
+        if (s.lastLaunch)
+            (void)hipEventDestroy(s.lastLaunch);
+    if (c->cacheArena)
+        (void)hipFree(c->cacheArena);
+    if (c->copyDone)
+        (void)hipEventDestroy(c->copyDone);
+    if (c->copyStream)
+        (void)hipStreamDestroy(c->copyStream);
     for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork })
         if (b->ptr)
             (void)hipFree(b->ptr);
@@ -291,31 +303,34 @@ int pgpu_upload_mesh(pgpu_ctx* c, const float* positions, size_t n_vertices, con
     return PGPU_OK;
 }
 
-int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
-    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id)
+// Validation shared by pgpu_upload_bvh8 and pgpu_stage_bvh8 + the gather of every leaf slot's triangle (see Bvh8Dev in kernels.h).
+static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, std::vector<float>& tris, Bvh8Dev& d)
 {
-    if (!c || !leaf_indices || !objs || !bvh_id || n_indices == 0 || n_objs == 0 || (n_nodes && !nodes256))
-        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: null or empty argument");
+    auto bad = [&](int code, const char* what) {
+        c->err = std::string(who) + ": " + what;
+        return code;
+    };
+    if (!leaf_indices || !objs || n_indices == 0 || n_objs == 0 || (n_nodes && !nodes256))
+        return bad(PGPU_ERR_INVALID, "null or empty argument");
     if (n_nodes >= (1u << 29) || n_indices >= (1u << 29))
-        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: more than 2^29 nodes or leaf indices");
-    HIP_TRY(c, hipSetDevice(c->device));
+        return bad(PGPU_ERR_INVALID, "more than 2^29 nodes or leaf indices");
     const int depth = bvh8Depth(static_cast<const unsigned char*>(nodes256), n_nodes, n_indices, root_handle);
     if (depth < 0)
-        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: malformed tree (handle out of range or cycle)");
+        return bad(PGPU_ERR_INVALID, "malformed tree (handle out of range or cycle)");
     if (7 * depth + 8 > 96) // the 96-entry traversal stack of wive_bvh8_impl.h:74-75
-        return fail(c, PGPU_ERR_DEPTH, "pgpu_upload_bvh8: more than 12 nested inner nodes");
-    // gather every leaf slot's triangle once (see Bvh8Dev in kernels.h)
-    std::vector<float> tris(n_indices * 12, 0.0f);
+        return bad(PGPU_ERR_DEPTH, "more than 12 nested inner nodes");
+    tris.assign(n_indices * 12, 0.0f);
     for (size_t s = 0; s < n_indices; ++s) {
         const uint32_t obj = leaf_indices[s];
         if (obj >= n_objs)
-            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: leaf index beyond the leaf-object table");
+            return bad(PGPU_ERR_INVALID, "leaf index beyond the leaf-object table");
         const pgpu_leafobj lo = objs[obj];
         if (lo.mesh >= c->meshes.size())
-            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: unknown mesh id");
+            return bad(PGPU_ERR_INVALID, "unknown mesh id");
         const HostMesh& m = c->meshes[lo.mesh];
         if (size_t(lo.prim) * 3 + 2 >= m.idx.size())
-            return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: primitive id out of range");
+            return bad(PGPU_ERR_INVALID, "primitive id out of range");
         float* t = &tris[s * 12];
         for (int k = 0; k < 3; ++k) {
             const float* p = &m.pos[size_t(m.idx[size_t(lo.prim) * 3 + size_t(k)]) * 3];
@@ -325,10 +340,29 @@ int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const ui
         }
         std::memcpy(&t[3], &obj, 4);
     }
+    d = Bvh8Dev {};
+    d.root = root_handle;
+    d.n_nodes = uint32_t(n_nodes);
+    d.n_slots = uint32_t(n_indices);
+    d.depth = uint32_t(depth);
+    d.needs_exact = bvh8NeedsExact(static_cast<const unsigned char*>(nodes256), n_nodes) ? 1u : 0u;
+    return PGPU_OK;
+}
+
+int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id)
+{
+    if (!c || !bvh_id)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<float> tris;
     Bvh8Dev d {};
+    int rc = prepareBvh8(c, "pgpu_upload_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, tris, d);
+    if (rc != PGPU_OK)
+        return rc;
     unsigned char* devNodes = nullptr;
     float* devTris = nullptr;
-    int rc = uploadArray(c, static_cast<const unsigned char*>(nodes256), n_nodes * 256, &devNodes);
+    rc = uploadArray(c, static_cast<const unsigned char*>(nodes256), n_nodes * 256, &devNodes);
     if (rc != PGPU_OK)
         return rc;
     rc = uploadArray(c, tris.data(), tris.size(), &devTris);
@@ -336,14 +370,67 @@ int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const ui
         return rc;
     d.nodes = devNodes;
     d.tris = reinterpret_cast<const unsigned char*>(devTris);
-    d.root = root_handle;
-    d.n_nodes = uint32_t(n_nodes);
-    d.n_slots = uint32_t(n_indices);
-    d.depth = uint32_t(depth);
-    d.needs_exact = bvh8NeedsExact(static_cast<const unsigned char*>(nodes256), n_nodes) ? 1u : 0u;
     c->bvhs.push_back(d);
+    c->staged.resize(c->bvhs.size());
     c->bvhTableDirty = true;
     *bvh_id = uint32_t(c->bvhs.size() - 1);
+    return PGPU_OK;
+}
+
+int pgpu_stage_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id)
+{
+    if (!c || !bvh_id)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_stage_bvh8: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<float> tris;
+    Bvh8Dev d {};
+    const int rc = prepareBvh8(c, "pgpu_stage_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, tris, d);
+    if (rc != PGPU_OK)
+        return rc;
+    StagedBvh s;
+    s.nodeBytes = (n_nodes * 256 + 255) & ~size_t(255);
+    s.triBytes = (tris.size() * 4 + 255) & ~size_t(255);
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s.host), std::max<size_t>(s.nodeBytes + s.triBytes, 256), hipHostMallocDefault));
+    std::memset(s.host, 0, s.nodeBytes + s.triBytes);
+    if (n_nodes)
+        std::memcpy(s.host, nodes256, n_nodes * 256);
+    std::memcpy(s.host + s.nodeBytes, tris.data(), tris.size() * 4);
+    c->bvhs.push_back(d); // nodes / tris stay null until the BVH sits in a cache slot
+    c->staged.resize(c->bvhs.size());
+    c->staged.back() = s;
+    c->nStaged++;
+    c->bvhTableDirty = true;
+    *bvh_id = uint32_t(c->bvhs.size() - 1);
+    return PGPU_OK;
+}
+
+int pgpu_set_leaf_cache(pgpu_ctx* c, size_t bytes)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    // the cache is rebuilt (empty) at the next pgpu_trace
+    for (StagedBvh& s : c->staged)
+        if (s.host && s.slot >= 0) {
+            s.slot = -1;
+        }
+    for (size_t i = 0; i < c->bvhs.size(); ++i)
+        if (i < c->staged.size() && c->staged[i].host) {
+            c->bvhs[i].nodes = nullptr;
+            c->bvhs[i].tris = nullptr;
+        }
+    for (CacheSlot& s : c->slots)
+        if (s.lastLaunch)
+            (void)hipEventDestroy(s.lastLaunch);
+    c->slots.clear();
+    if (c->cacheArena)
+        HIP_TRY(c, hipFree(c->cacheArena));
+    c->cacheArena = nullptr;
+    c->slotBytes = 0;
+    c->cacheBudget = bytes;
+    c->bvhTableDirty = true;
     return PGPU_OK;
 }
 
@@ -354,6 +441,8 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: null argument");
     if (bvh_id >= c->bvhs.size())
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_bvh8: unknown bvh id");
+    if (bvh_id < c->staged.size() && c->staged[bvh_id].host)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_bvh8: this BVH is staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams it");
     if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: kind must be PGPU_CLOSEST or PGPU_ANY");
     if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)

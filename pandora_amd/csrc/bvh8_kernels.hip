@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                     ldsStoreU2(stackBase, make_uint2(bd.root, __float_as_uint(0.0f))); // :80-82
                 sp = 1;
                 hitMark = 0;
-                st = bvhId < a.n_bvhs ? 1 : 0; // (a work item whose geometry is not resident here is dropped)
+                st = (bvhId < a.n_bvhs && bd.nodes != nullptr) ? 1 : 0; // (a work item whose geometry is not resident here is dropped)
             }
             if (STATS)
                 statRefill += (lane == 0);

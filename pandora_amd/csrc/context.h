@@ -15,6 +15,20 @@ struct DeviceBuffer {
     size_t bytes = 0;
 };
 
+// A bottom-level BVH kept in pinned host memory and copied into an HBM cache slot when rays reach it
+// (BASELINE config 5; the reference's CachedBVH::doMakeResident / doEvict, offline_bvh_cache.cpp:127-148).
+struct StagedBvh {
+    unsigned char* host = nullptr; // pinned: the 256-byte nodes, then (256-aligned) the 48-byte triangle records
+    size_t nodeBytes = 0, triBytes = 0;
+    int slot = -1; // cache slot it currently occupies
+};
+struct CacheSlot {
+    int bvh = -1;
+    uint64_t lastUse = 0;
+    hipEvent_t lastLaunch = nullptr; // recorded on the compute stream after the last launch that read the slot
+    bool launched = false;
+};
+
 struct pgpu_ctx {
     int device = 0;
     int numCUs = 256;
@@ -52,6 +66,16 @@ struct pgpu_ctx {
     DeviceBuffer work; // per-ray traversal state + queues, grown on demand
     DeviceBuffer blockWork; // scratch of the building-block entry points (work item -> bvh id)
     unsigned long long* topCounters = nullptr; // SVDAG tests / culled of pgpu_top_episode calls (device)
+
+    // streamed leaves
+    std::vector<StagedBvh> staged;               // indexed by bvh id; host == nullptr for HBM-resident ones
+    std::vector<pandora_hip::TopLeafDev> topLeavesHost;
+    size_t nStaged = 0, cacheBudget = 0, slotBytes = 0;
+    unsigned char* cacheArena = nullptr;
+    std::vector<CacheSlot> slots;
+    hipStream_t copyStream = nullptr;
+    hipEvent_t copyDone = nullptr;
+    uint64_t useClock = 0;
 };
 
 namespace pandora_hip {

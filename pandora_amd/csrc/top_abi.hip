@@ -56,6 +56,72 @@ int ensureBuf(pgpu_ctx* c, DeviceBuffer& b, size_t bytes)
 
 size_t alignUp(size_t v) { return (v + 255) & ~size_t(255); }
 
+// Builds the (empty) HBM cache for staged BVHs: equal slots, each large enough for the largest staged image.
+int ensureLeafCache(pgpu_ctx* c)
+{
+    if (c->nStaged == 0 || c->cacheArena)
+        return PGPU_OK;
+    size_t slotBytes = 0;
+    for (const StagedBvh& s : c->staged)
+        if (s.host)
+            slotBytes = std::max(slotBytes, s.nodeBytes + s.triBytes);
+    slotBytes = std::max<size_t>(alignUp(slotBytes), 256);
+    size_t nSlots = c->nStaged;
+    if (c->cacheBudget) {
+        if (c->cacheBudget < slotBytes)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_trace: the leaf cache (pgpu_set_leaf_cache) is smaller than the largest staged BVH");
+        nSlots = std::min(nSlots, c->cacheBudget / slotBytes);
+    }
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->cacheArena), nSlots * slotBytes));
+    c->slotBytes = slotBytes;
+    c->slots.assign(nSlots, CacheSlot {});
+    for (CacheSlot& s : c->slots)
+        HIP_TRY(c, hipEventCreateWithFlags(&s.lastLaunch, hipEventDisableTiming));
+    if (!c->copyStream)
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+    if (!c->copyDone)
+        HIP_TRY(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
+    return PGPU_OK;
+}
+
+// Makes staged BVH `id` resident (no-op if it is); `pinned` marks the slots the current launch group needs.
+// Copies run on the copy stream, behind the last launch that read the slot being recycled.
+int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* copied)
+{
+    StagedBvh& s = c->staged[id];
+    if (s.slot >= 0) {
+        pinned[size_t(s.slot)] = 1;
+        c->slots[size_t(s.slot)].lastUse = ++c->useClock;
+        return PGPU_OK;
+    }
+    int victim = -1;
+    for (size_t i = 0; i < c->slots.size(); ++i)
+        if (!pinned[i] && (victim < 0 || c->slots[i].lastUse < c->slots[size_t(victim)].lastUse))
+            victim = int(i);
+    if (victim < 0)
+        return fail(c, PGPU_ERR_INVALID, "leaf cache: no free slot (internal)");
+    CacheSlot& slot = c->slots[size_t(victim)];
+    if (slot.bvh >= 0) { // evict (CachedBVH::doEvict)
+        c->staged[size_t(slot.bvh)].slot = -1;
+        c->bvhs[size_t(slot.bvh)].nodes = nullptr;
+        c->bvhs[size_t(slot.bvh)].tris = nullptr;
+    }
+    if (slot.launched)
+        HIP_TRY(c, hipStreamWaitEvent(c->copyStream, slot.lastLaunch, 0));
+    unsigned char* dst = c->cacheArena + size_t(victim) * c->slotBytes;
+    HIP_TRY(c, hipMemcpyAsync(dst, s.host, s.nodeBytes + s.triBytes, hipMemcpyHostToDevice, c->copyStream));
+    c->bvhs[id].nodes = dst;
+    c->bvhs[id].tris = dst + s.nodeBytes;
+    s.slot = victim;
+    slot.bvh = int(id);
+    slot.lastUse = ++c->useClock;
+    pinned[size_t(victim)] = 1;
+    c->counters.leaf_loads += 1;
+    c->counters.streamed_bytes += s.nodeBytes + s.triBytes;
+    *copied = true;
+    return PGPU_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -171,6 +237,7 @@ int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint
     c->top.n_nodes = uint32_t(n_nodes);
     c->top.n_leaves = uint32_t(n_leaves);
     c->haveTop = true;
+    c->topLeavesHost = lv;
     c->topHasRemoteLeaves = remote;
     return PGPU_OK;
 }
@@ -338,6 +405,15 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         deepest = std::max(deepest, b.depth);
     ba.stats = c->stats ? c->statsDev : nullptr;
 
+    const bool streaming = c->nStaged > 0;
+    rc = ensureLeafCache(c);
+    if (rc != PGPU_OK)
+        return rc;
+    std::vector<uint32_t> hLeafCount, hLeafStart;
+    std::vector<uint8_t> pinned;
+    uint64_t leafLoads0 = c->counters.leaf_loads = 0, streamed0 = c->counters.streamed_bytes = 0;
+    (void)leafLoads0;
+    (void)streamed0;
     uint64_t rounds = 0, leafVisits = 0;
     uint32_t nActive = uint32_t(n);
     const uint32_t* active = nullptr; // round 0: every ray, identity order
@@ -363,13 +439,80 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         ++rounds;
         leafVisits += parked;
         ba.work_ray = workRayOut;
-        HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
-        ba.n_work = parked;
-        uint32_t blocks = 1;
-        rc = planBvh8Launch(c, deepest, parked, ba, &blocks);
-        if (rc != PGPU_OK)
-            return rc;
-        HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+        if (!streaming) {
+            HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+            ba.n_work = parked;
+            uint32_t blocks = 1;
+            rc = planBvh8Launch(c, deepest, parked, ba, &blocks);
+            if (rc != PGPU_OK)
+                return rc;
+            HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+        } else {
+            // Leaves streamed from host memory: the work list is sorted by batching point, so consecutive points whose
+            // BVHs fit the cache together form one launch; the copies of the next group run on the copy stream while
+            // this group traces (a slot is recycled only behind the last launch that read it).
+            hLeafCount.resize(nl);
+            hLeafStart.resize(nl);
+            HIP_TRY(c, hipMemcpyAsync(hLeafCount.data(), dLeafCount, nl * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipMemcpyAsync(hLeafStart.data(), dLeafStart, nl * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipStreamSynchronize(stream));
+            const uint32_t* workRayAll = workRayOut;
+            size_t l = 0;
+            while (l < nl) {
+                if (hLeafCount[l] == 0) {
+                    ++l;
+                    continue;
+                }
+                pinned.assign(c->slots.size(), 0);
+                size_t pinnedCount = 0;
+                bool copied = false;
+                const size_t first = l;
+                size_t last = l;
+                std::vector<uint32_t> touched;
+                for (; l < nl; ++l) {
+                    if (hLeafCount[l] == 0)
+                        continue;
+                    const uint32_t id = c->topLeavesHost[l].bvh;
+                    if (id < c->staged.size() && c->staged[id].host) {
+                        const int slot = c->staged[id].slot;
+                        if (slot < 0 || !pinned[size_t(slot)]) {
+                            if (pinnedCount == c->slots.size())
+                                break; // the cache is full of BVHs this launch needs: launch, then go on
+                            ++pinnedCount;
+                            rc = makeResident(c, id, pinned, &copied);
+                            if (rc != PGPU_OK)
+                                return rc;
+                            touched.push_back(id);
+                        }
+                    }
+                    last = l;
+                }
+                const uint32_t lo = hLeafStart[first], hi = hLeafStart[last] + hLeafCount[last];
+                if (copied) {
+                    HIP_TRY(c, hipEventRecord(c->copyDone, c->copyStream));
+                    HIP_TRY(c, hipStreamWaitEvent(stream, c->copyDone, 0));
+                }
+                for (uint32_t id : touched) // device copy of the table entries that moved
+                    HIP_TRY(c, hipMemcpyAsync(c->bvhTable + id, &c->bvhs[id], sizeof(Bvh8Dev), hipMemcpyHostToDevice, stream));
+                HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+                ba.work_ray = workRayAll + lo;
+                ba.work_bvh = dWorkBvh + lo;
+                ba.work_tag = dWorkLeaf + lo;
+                ba.n_work = hi - lo;
+                uint32_t blocks = 1;
+                rc = planBvh8Launch(c, deepest, hi - lo, ba, &blocks);
+                if (rc != PGPU_OK)
+                    return rc;
+                HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+                for (uint32_t id : touched) {
+                    CacheSlot& s = c->slots[size_t(c->staged[id].slot)];
+                    HIP_TRY(c, hipEventRecord(s.lastLaunch, stream));
+                    s.launched = true;
+                }
+            }
+            ba.work_bvh = dWorkBvh;
+            ba.work_tag = dWorkLeaf;
+        }
         active = workRayOut;
         nActive = parked;
     }
@@ -391,7 +534,10 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     HIP_TRY(c, hipMemcpyAsync(cnt, dCounters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
     HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
+    const uint64_t leafLoads = c->counters.leaf_loads, streamedBytes = c->counters.streamed_bytes;
     c->counters = pgpu_counters {};
+    c->counters.leaf_loads = leafLoads;
+    c->counters.streamed_bytes = streamedBytes;
     c->counters.svdag_tests = cnt[0];
     c->counters.svdag_culled = cnt[1];
     c->counters.leaf_visits = leafVisits;
