@@ -230,9 +230,8 @@ void pgpu_shutdown(pgpu_ctx* c)
     for (StagedBvh& s : c->staged)
         if (s.host)
             (void)hipHostFree(s.host);
-    for (CacheSlot& s : c->slots)
-        if (s.lastLaunch)
-            (void)hipEventDestroy(s.lastLaunch);
+    for (hipEvent_t e : c->launchEvents)
+        (void)hipEventDestroy(e);
     if (c->cacheArena)
         (void)hipFree(c->cacheArena);
     if (c->copyDone)
@@ -421,9 +420,6 @@ int pgpu_set_leaf_cache(pgpu_ctx* c, size_t bytes)
             c->bvhs[i].nodes = nullptr;
             c->bvhs[i].tris = nullptr;
         }
-    for (CacheSlot& s : c->slots)
-        if (s.lastLaunch)
-            (void)hipEventDestroy(s.lastLaunch);
     c->slots.clear();
     if (c->cacheArena)
         HIP_TRY(c, hipFree(c->cacheArena));

@@ -25,8 +25,7 @@ struct StagedBvh {
 struct CacheSlot {
     int bvh = -1;
     uint64_t lastUse = 0;
-    hipEvent_t lastLaunch = nullptr; // recorded on the compute stream after the last launch that read the slot
-    bool launched = false;
+    int lastLaunch = -1; // index into launchEvents: recorded on the compute stream after the last launch that read the slot
 };
 
 struct pgpu_ctx {
@@ -75,6 +74,8 @@ struct pgpu_ctx {
     std::vector<CacheSlot> slots;
     hipStream_t copyStream = nullptr;
     hipEvent_t copyDone = nullptr;
+    std::vector<hipEvent_t> launchEvents; // ring: one event per bottom-level launch of the streaming path (a later record of the
+    size_t launchEventNext = 0;           // same ring entry is a later point of the compute stream, so waiting on it stays safe)
     uint64_t useClock = 0;
 };
 

@@ -75,8 +75,11 @@ int ensureLeafCache(pgpu_ctx* c)
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->cacheArena), nSlots * slotBytes));
     c->slotBytes = slotBytes;
     c->slots.assign(nSlots, CacheSlot {});
-    for (CacheSlot& s : c->slots)
-        HIP_TRY(c, hipEventCreateWithFlags(&s.lastLaunch, hipEventDisableTiming));
+    if (c->launchEvents.empty()) {
+        c->launchEvents.resize(64);
+        for (hipEvent_t& e : c->launchEvents)
+            HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     if (!c->copyStream)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
     if (!c->copyDone)
@@ -106,8 +109,8 @@ int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* c
         c->bvhs[size_t(slot.bvh)].nodes = nullptr;
         c->bvhs[size_t(slot.bvh)].tris = nullptr;
     }
-    if (slot.launched)
-        HIP_TRY(c, hipStreamWaitEvent(c->copyStream, slot.lastLaunch, 0));
+    if (slot.lastLaunch >= 0)
+        HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->launchEvents[size_t(slot.lastLaunch)], 0));
     unsigned char* dst = c->cacheArena + size_t(victim) * c->slotBytes;
     HIP_TRY(c, hipMemcpyAsync(dst, s.host, s.nodeBytes + s.triBytes, hipMemcpyHostToDevice, c->copyStream));
     c->bvhs[id].nodes = dst;
@@ -468,7 +471,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 bool copied = false;
                 const size_t first = l;
                 size_t last = l;
-                std::vector<uint32_t> touched;
+                std::vector<uint32_t> touched, movedIds;
                 for (; l < nl; ++l) {
                     if (hLeafCount[l] == 0)
                         continue;
@@ -479,10 +482,14 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                             if (pinnedCount == c->slots.size())
                                 break; // the cache is full of BVHs this launch needs: launch, then go on
                             ++pinnedCount;
-                            rc = makeResident(c, id, pinned, &copied);
+                            bool moved = false;
+                            rc = makeResident(c, id, pinned, &moved);
                             if (rc != PGPU_OK)
                                 return rc;
+                            copied = copied || moved;
                             touched.push_back(id);
+                            if (moved)
+                                movedIds.push_back(id);
                         }
                     }
                     last = l;
@@ -492,7 +499,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                     HIP_TRY(c, hipEventRecord(c->copyDone, c->copyStream));
                     HIP_TRY(c, hipStreamWaitEvent(stream, c->copyDone, 0));
                 }
-                for (uint32_t id : touched) // device copy of the table entries that moved
+                for (uint32_t id : movedIds) // device copy of the table entries that moved
                     HIP_TRY(c, hipMemcpyAsync(c->bvhTable + id, &c->bvhs[id], sizeof(Bvh8Dev), hipMemcpyHostToDevice, stream));
                 HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
                 ba.work_ray = workRayAll + lo;
@@ -504,10 +511,11 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 if (rc != PGPU_OK)
                     return rc;
                 HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
-                for (uint32_t id : touched) {
-                    CacheSlot& s = c->slots[size_t(c->staged[id].slot)];
-                    HIP_TRY(c, hipEventRecord(s.lastLaunch, stream));
-                    s.launched = true;
+                if (!touched.empty()) {
+                    const size_t ev = c->launchEventNext++ % c->launchEvents.size();
+                    HIP_TRY(c, hipEventRecord(c->launchEvents[ev], stream));
+                    for (uint32_t id : touched)
+                        c->slots[size_t(c->staged[id].slot)].lastLaunch = int(ev);
                 }
             }
             ba.work_bvh = dWorkBvh;
