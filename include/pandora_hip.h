@@ -208,6 +208,22 @@ int pgpu_top_episode(pgpu_ctx*, int kind, const pgpu_rays* rays, const uint32_t*
 int pgpu_trace_leaves(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, const uint32_t* work_ray, const uint32_t* work_leaf,
     size_t n_work, const pgpu_hits* hits, uint32_t* any_hit, void* stream);
 
+/* Device-side record handling of the same loop (everything between two all-to-alls stays on the GPU). A record is 9
+ * dwords {ox oy oz dx dy dz tnear tfar leaf} with tfar = the ray's current t for closest hit; a result is 4 dwords
+ * {t, obj, u, v} (obj = PGPU_MISS: nothing closer) or 1 dword {hit} for any hit.
+ * pgpu_route_pack:         groups the work items that parked (parked_leaf != PGPU_MISS) by owner_of_leaf[leaf] (device
+ *                          array, one rank < world <= 64 per batching point): dest_counts_host[world] (host, written
+ *                          before the call returns - the one synchronisation), records in destination order, and per
+ *                          record the home ray id and the batching point (sent_slot doubles as next round's active list).
+ * pgpu_trace_leaf_records: owner side: k received records through the named (resident) batching points -> k results,
+ *                          same order.
+ * pgpu_route_merge:        home side: returned results replace the hit record of rays that found something closer. */
+int pgpu_route_pack(pgpu_ctx*, const pgpu_rays* rays, const float* t_state, const uint32_t* active, const uint32_t* parked_leaf, size_t n_active,
+    const uint32_t* owner_of_leaf, uint32_t world, uint32_t* dest_counts_host, float* records, uint32_t* sent_slot, uint32_t* sent_leaf, void* stream);
+int pgpu_trace_leaf_records(pgpu_ctx*, int kind, int tri_mode, const float* records, size_t k, float* results, void* stream);
+int pgpu_route_merge(pgpu_ctx*, int kind, const float* results, const uint32_t* sent_slot, const uint32_t* sent_leaf, size_t k,
+    const pgpu_hits* hits, uint32_t* any_hit, void* stream);
+
 /* Diagnostics: device time of the traversal kernels of the last trace call on this context, measured
  * with HIP events on the stream they ran on (ms); enables/disables visit counters. */
 float pgpu_last_kernel_ms(const pgpu_ctx*);

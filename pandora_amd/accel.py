@@ -339,6 +339,23 @@ class Context:
         _check(self._L.pgpu_trace_leaves(self._h, kind, tri_mode, C.byref(r), capi.ptr(work_ray), capi.ptr(work_leaf), n_work,
                                          C.byref(h) if h is not None else None, capi.ptr(any_hit), stream), self._h)
 
+    def route_pack(self, rays, t_state, active, parked_leaf, n_active: int, owner_dev, world: int, records, sent_slot, sent_leaf, stream: int = 0) -> np.ndarray:
+        r, _ = self._rays_struct(rays)
+        counts = np.zeros(world, np.uint32)
+        _check(self._L.pgpu_route_pack(self._h, C.byref(r), capi.ptr(t_state), capi.ptr(active), capi.ptr(parked_leaf), n_active, capi.ptr(owner_dev), world,
+                                       counts.ctypes.data, capi.ptr(records), capi.ptr(sent_slot), capi.ptr(sent_leaf), stream), self._h)
+        return counts
+
+    def trace_leaf_records(self, kind: int, tri_mode: int, records, k: int, results, stream: int = 0):
+        _check(self._L.pgpu_trace_leaf_records(self._h, kind, tri_mode, capi.ptr(records), k, capi.ptr(results), stream), self._h)
+
+    def route_merge(self, kind: int, results, sent_slot, sent_leaf, k: int, hits: dict | None, any_hit=None, stream: int = 0):
+        h = None
+        if hits is not None:
+            h = capi.Hits(capi.ptr(hits["t"]), capi.ptr(hits["obj"]), capi.ptr(hits["leaf"]), capi.ptr(hits["u"]), capi.ptr(hits["v"]), 0)
+        _check(self._L.pgpu_route_merge(self._h, kind, capi.ptr(results), capi.ptr(sent_slot), capi.ptr(sent_leaf), k, C.byref(h) if h is not None else None,
+                                        capi.ptr(any_hit), stream), self._h)
+
     def sync(self, stream: int = 0):
         _check(self._L.pgpu_sync(self._h, stream), self._h)
 

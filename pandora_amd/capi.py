@@ -91,6 +91,10 @@ SYMBOLS = {
     "pgpu_ray_state_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
     "pgpu_top_episode": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Rays), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgpu_trace_leaves": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
+    "pgpu_route_pack": (C.c_int, [C.c_void_p, C.POINTER(Rays), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgpu_trace_leaf_records": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pgpu_route_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
     "pgpu_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "pgpu_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgpu_set_stats": (C.c_int, [C.c_void_p, C.c_int]),

@@ -238,7 +238,7 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipEventDestroy(c->copyDone);
     if (c->copyStream)
         (void)hipStreamDestroy(c->copyStream);
-    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork })
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork })
         if (b->ptr)
             (void)hipFree(b->ptr);
     (void)hipEventDestroy(c->ev0);

@@ -64,6 +64,7 @@ struct pgpu_ctx {
     bool topCountersDirty = false; // pgpu_top_episode ran since the counters were last read
     DeviceBuffer work; // per-ray traversal state + queues, grown on demand
     DeviceBuffer blockWork; // scratch of the building-block entry points (work item -> bvh id)
+    DeviceBuffer routeWork; // scratch of pgpu_trace_leaf_records
     unsigned long long* topCounters = nullptr; // SVDAG tests / culled of pgpu_top_episode calls (device)
 
     // streamed leaves

@@ -100,6 +100,21 @@ hipError_t launchLeafToBvh(const uint32_t* workLeaf, const TopLeafDev* leaves, u
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);
 
+// route_kernels.hip: record packing for the leaf-sharded loop
+uint32_t routeMaxRanks();
+hipError_t launchRouteCount(const uint32_t* parkedLeaf, uint32_t n, const uint32_t* owner, uint32_t nLeaves, uint32_t world, uint32_t* counts,
+    uint32_t blocks, hipStream_t stream);
+hipError_t launchRouteScatter(const float* const rays[8], const uint32_t* active, const uint32_t* parkedLeaf, uint32_t n, const uint32_t* owner,
+    uint32_t nLeaves, uint32_t world, const uint32_t* startsHost, uint32_t* fill, float* records, uint32_t* sentSlot, uint32_t* sentLeaf,
+    uint32_t blocks, hipStream_t stream);
+hipError_t launchUnpackRecords(const float* records, uint32_t k, float* soa, uint32_t* workLeaf, float* t, uint32_t* obj, uint32_t* anyHit,
+    uint32_t blocks, hipStream_t stream);
+hipError_t launchPackResults(uint32_t k, const float* t, const uint32_t* obj, const float* u, const float* v, const uint32_t* anyHit, float* results,
+    uint32_t blocks, hipStream_t stream);
+hipError_t launchMergeResults(uint32_t k, const float* results, const uint32_t* sentSlot, const uint32_t* sentLeaf, float* t, uint32_t* obj,
+    uint32_t* leaf, float* u, float* v, uint32_t* anyHit, uint32_t blocks, hipStream_t stream);
+hipError_t launchKeyCount(const uint32_t* keys, uint32_t n, uint32_t nKeys, uint32_t* counts, uint32_t blocks, hipStream_t stream);
+
 size_t bvh8TraceLdsBytes(uint32_t stackEntries);
 inline uint32_t stackEntriesForDepth(uint32_t depth)
 {

@@ -1,0 +1,217 @@
+// C ABI of the leaf-sharded loop's device-side record handling (pandora_amd/sharded.py drives it between all-to-alls).
+#include "context.h"
+#include <algorithm>
+#include <cstring>
+
+using namespace pandora_hip;
+
+namespace {
+
+int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                               \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess)                            \
+            return fail((ctx), PGPU_ERR_HIP, #call, e_); \
+    } while (0)
+
+int ensureBuf(pgpu_ctx* c, DeviceBuffer& b, size_t bytes)
+{
+    if (b.bytes >= bytes)
+        return PGPU_OK;
+    if (b.ptr)
+        HIP_TRY(c, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    HIP_TRY(c, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return PGPU_OK;
+}
+
+size_t alignUp(size_t v) { return (v + 255) & ~size_t(255); }
+
+uint32_t gridFor(const pgpu_ctx* c, size_t n) { return uint32_t(std::max<size_t>(1, std::min<size_t>((n + 255) / 256, size_t(c->numCUs) * 8))); }
+
+} // namespace
+
+extern "C" {
+
+int pgpu_route_pack(pgpu_ctx* c, const pgpu_rays* rays, const float* t_state, const uint32_t* active, const uint32_t* parked_leaf, size_t n_active,
+    const uint32_t* owner_of_leaf, uint32_t world, uint32_t* dest_counts_host, float* records, uint32_t* sent_slot, uint32_t* sent_leaf, void* stream_)
+{
+    if (!c || !dest_counts_host || (n_active && (!rays || !parked_leaf || !owner_of_leaf || !records || !sent_slot || !sent_leaf)))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: null argument");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_route_pack: no top-level structure uploaded");
+    if (world == 0 || world > routeMaxRanks())
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: between 1 and 64 ranks");
+    if (n_active > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: batch too large");
+    std::memset(dest_counts_host, 0, world * sizeof(uint32_t));
+    if (n_active == 0)
+        return PGPU_OK;
+    const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, t_state ? t_state : rays->tfar };
+    for (const float* p : rp)
+        if (!p)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: null ray array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    int rc = ensureBuf(c, c->blockWork, alignUp(n_active * 4) + 1024);
+    if (rc != PGPU_OK)
+        return rc;
+    // the two small counter arrays sit behind the work-item scratch
+    uint32_t* dCounts = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->blockWork.ptr) + c->blockWork.bytes - 1024);
+    uint32_t* dFill = dCounts + 64;
+    HIP_TRY(c, hipMemsetAsync(dCounts, 0, 512, stream));
+    const uint32_t blocks = gridFor(c, n_active);
+    HIP_TRY(c, launchRouteCount(parked_leaf, uint32_t(n_active), owner_of_leaf, c->top.n_leaves, world, dCounts, blocks, stream));
+    HIP_TRY(c, hipMemcpyAsync(dest_counts_host, dCounts, world * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    uint32_t starts[64] = { 0 };
+    uint32_t run = 0;
+    for (uint32_t d = 0; d < world; ++d) {
+        starts[d] = run;
+        run += dest_counts_host[d];
+    }
+    if (run == 0)
+        return PGPU_OK;
+    HIP_TRY(c, launchRouteScatter(rp, active, parked_leaf, uint32_t(n_active), owner_of_leaf, c->top.n_leaves, world, starts, dFill, records, sent_slot,
+                   sent_leaf, blocks, stream));
+    return PGPU_OK;
+}
+
+int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, void* stream_)
+{
+    if (!c || (k && (!records || !results)))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: null argument");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no top-level structure uploaded");
+    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: kind must be PGPU_CLOSEST or PGPU_ANY");
+    if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: unknown triangle test");
+    if (k > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: batch too large");
+    if (k == 0)
+        return PGPU_OK;
+    if (c->bvhs.empty())
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no bottom-level BVH is resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    // scratch: SoA rays 8k, t/u/v 3k, obj/leaf/any 3k, workLeaf, sorted workRay/workBvh/workLeaf 3k, per-leaf count/start/fill, total
+    const size_t nl = c->top.n_leaves;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += alignUp(bytes);
+        return at;
+    };
+    const size_t oSoa = carve(k * 32), oT = carve(k * 4), oU = carve(k * 4), oV = carve(k * 4), oObj = carve(k * 4), oLeaf = carve(k * 4), oAny = carve(k * 4);
+    const size_t oWl = carve(k * 4), oSr = carve(k * 4), oSb = carve(k * 4), oSl = carve(k * 4);
+    const size_t oCnt = carve(nl * 4), oStart = carve(nl * 4), oFill = carve(nl * 4), oTotal = carve(256);
+    int rc = ensureBuf(c, c->routeWork, off);
+    if (rc != PGPU_OK)
+        return rc;
+    unsigned char* wb = static_cast<unsigned char*>(c->routeWork.ptr);
+    float* soa = reinterpret_cast<float*>(wb + oSoa);
+    float *t = reinterpret_cast<float*>(wb + oT), *u = reinterpret_cast<float*>(wb + oU), *v = reinterpret_cast<float*>(wb + oV);
+    uint32_t *obj = reinterpret_cast<uint32_t*>(wb + oObj), *leaf = reinterpret_cast<uint32_t*>(wb + oLeaf), *any = reinterpret_cast<uint32_t*>(wb + oAny);
+    uint32_t *wl = reinterpret_cast<uint32_t*>(wb + oWl), *sr = reinterpret_cast<uint32_t*>(wb + oSr), *sb = reinterpret_cast<uint32_t*>(wb + oSb),
+             *sl = reinterpret_cast<uint32_t*>(wb + oSl);
+    uint32_t *cnt = reinterpret_cast<uint32_t*>(wb + oCnt), *start = reinterpret_cast<uint32_t*>(wb + oStart), *fill = reinterpret_cast<uint32_t*>(wb + oFill),
+             *total = reinterpret_cast<uint32_t*>(wb + oTotal);
+    if (c->bvhTableDirty) {
+        if (c->bvhTableCap < c->bvhs.size()) {
+            if (c->bvhTable)
+                HIP_TRY(c, hipFree(c->bvhTable));
+            c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
+        }
+        HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
+        c->bvhTableDirty = false;
+    }
+    const uint32_t blocks = gridFor(c, k);
+    const bool closest = kind == PGPU_CLOSEST;
+    HIP_TRY(c, launchUnpackRecords(records, uint32_t(k), soa, wl, closest ? t : nullptr, obj, closest ? nullptr : any, blocks, stream));
+    // sort the work by batching point so that the rays of one leaf are adjacent (histogram, scan, scatter)
+    HIP_TRY(c, hipMemsetAsync(cnt, 0, nl * 4, stream));
+    HIP_TRY(c, launchKeyCount(wl, uint32_t(k), uint32_t(nl), cnt, blocks, stream));
+    HIP_TRY(c, launchLeafScan(cnt, start, fill, uint32_t(nl), total, stream));
+    Bvh8TraceArgs ba {};
+    ba.bvhs = c->bvhTable;
+    ba.work_ray = sr;
+    ba.work_bvh = sb;
+    ba.work_tag = sl;
+    ba.n_work = uint32_t(k); // (work items whose leaf id was out of range were not binned: the tail of the list is skipped below)
+    ba.ox = soa;
+    ba.oy = soa + k;
+    ba.oz = soa + 2 * k;
+    ba.dx = soa + 3 * k;
+    ba.dy = soa + 4 * k;
+    ba.dz = soa + 5 * k;
+    ba.tnear = soa + 6 * k;
+    ba.tfar_in = closest ? t : soa + 7 * k;
+    ba.t_out = t;
+    ba.obj_out = obj;
+    ba.leaf_out = leaf;
+    ba.u_out = u;
+    ba.v_out = v;
+    ba.any_out = any;
+    ba.cursor = c->cursor;
+    ba.chunk = c->chunk;
+    ba.init_miss = 0;
+    ba.stats = c->stats ? c->statsDev : nullptr;
+    uint32_t deepest = 0;
+    for (const Bvh8Dev& b : c->bvhs)
+        deepest = std::max(deepest, b.depth);
+    // every record names a valid leaf when it comes from pgpu_route_pack; a foreign record with a bad leaf id would leave
+    // a hole at the end of the sorted list, so mark the tail as "no bvh" first
+    HIP_TRY(c, hipMemsetAsync(sb, 0xFF, k * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(sr, 0, k * 4, stream));
+    HIP_TRY(c, launchBinByLeaf(nullptr, wl, uint32_t(k), uint32_t(nl), start, fill, c->top.leaves, sr, sb, sl, blocks, stream));
+    HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+    uint32_t nBlocks = 1;
+    rc = planBvh8Launch(c, deepest, k, ba, &nBlocks);
+    if (rc != PGPU_OK)
+        return rc;
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, nBlocks, stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    HIP_TRY(c, launchPackResults(uint32_t(k), t, obj, u, v, closest ? nullptr : any, results, blocks, stream));
+    return PGPU_OK;
+}
+
+int pgpu_route_merge(pgpu_ctx* c, int kind, const float* results, const uint32_t* sent_slot, const uint32_t* sent_leaf, size_t k,
+    const pgpu_hits* hits, uint32_t* any_hit, void* stream_)
+{
+    if (!c || (k && (!results || !sent_slot || !sent_leaf)))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: null argument");
+    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: kind must be PGPU_CLOSEST or PGPU_ANY");
+    if (kind == PGPU_CLOSEST && (!hits || !hits->t || !hits->obj || !hits->leaf || !hits->u || !hits->v))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: closest-hit needs t, obj, leaf, u, v arrays");
+    if (kind == PGPU_ANY && !any_hit)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: any-hit needs the any_hit array");
+    if (k > 0xFFFFFFF0ull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: batch too large");
+    if (k == 0)
+        return PGPU_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    const bool closest = kind == PGPU_CLOSEST;
+    HIP_TRY(c, launchMergeResults(uint32_t(k), results, sent_slot, sent_leaf, closest ? hits->t : nullptr, closest ? hits->obj : nullptr,
+                   closest ? hits->leaf : nullptr, closest ? hits->u : nullptr, closest ? hits->v : nullptr, closest ? nullptr : any_hit, gridFor(c, k), stream));
+    return PGPU_OK;
+}
+}

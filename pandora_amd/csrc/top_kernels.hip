@@ -350,14 +350,14 @@ __global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* __restric
 
 // scatter parked records into per-leaf contiguous ranges (the GPU form of the per-leaf queues)
 __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf,
-    uint32_t n, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
+    uint32_t n, uint32_t nLeaves, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
     const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t leaf = i < n ? parkedLeaf[i] : PGPU_MISS_ID;
-        const bool live = leaf != PGPU_MISS_ID;
+        const bool live = leaf < nLeaves; // (PGPU_MISS_ID = not parked; anything else out of range is ignored too)
         const KeyGroup kg = groupByKey(leaf, live);
         uint32_t base = 0;
         if (live && kg.leader == lane)
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __rest
     for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t leaf = i < hi ? parkedLeaf[i] : PGPU_MISS_ID;
-        const bool live = leaf != PGPU_MISS_ID;
+        const bool live = leaf < nLeaves;
         if (__ballot(live) != 0) {
             const KeyGroup kg = groupByKey(leaf, live);
             if (live && kg.leader == lane)
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __rest
     for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t leaf = i < hi ? parkedLeaf[i] : PGPU_MISS_ID;
-        const bool live = leaf != PGPU_MISS_ID;
+        const bool live = leaf < nLeaves;
         if (__ballot(live) == 0)
             continue;
         const KeyGroup kg = groupByKey(leaf, live);
@@ -498,7 +498,7 @@ hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, u
             leafFill, leaves, workRay, workBvh, workLeaf);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, leafStart, leafFill, leaves,
+    hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, nLeaves, leafStart, leafFill, leaves,
         workRay, workBvh, workLeaf);
     return hipGetLastError();
 }

@@ -63,8 +63,11 @@ def _all_to_all_rows(rows: torch.Tensor, send_counts: torch.Tensor, staging_cpu:
 class GpuEngine:
     """The product engine: pandora_hip through the C ABI, device tensors."""
 
-    def __init__(self, ctx, device: torch.device, tri_mode: int = capi.TRI_MT):
+    def __init__(self, ctx, device: torch.device, tri_mode: int = capi.TRI_MT, device_records: bool = True):
         self.ctx, self.device, self.tri_mode = ctx, device, tri_mode
+        # device_records: pack / unpack / merge the exchanged records with the library's kernels (pgpu_route_pack,
+        # pgpu_trace_leaf_records, pgpu_route_merge) instead of torch ops
+        self.device_records = device_records
         # The library's kernels and torch's own (sorting, gathering the records) must run on ONE stream so that they
         # are ordered: a side stream of torch's, handed to every library call. (Stream 0 would make the library fall
         # back to its private stream, which torch knows nothing about.)
@@ -110,6 +113,27 @@ class GpuEngine:
         self.ctx.trace_leaves(kind, self.tri_mode, rays, wr, wl, k, None, hit, stream=self.stream.cuda_stream)
         return hit
 
+    # -- device-side record path
+    def pack(self, kind, rays, active, parked, st, owner_dev, world):
+        n_active = int(active.shape[0])
+        rec = torch.empty((n_active, 9), dtype=torch.float32, device=self.device)
+        slot = torch.empty(n_active, dtype=torch.int32, device=self.device)
+        leaf = torch.empty(n_active, dtype=torch.int32, device=self.device)
+        counts = self.ctx.route_pack(rays, st.get("t") if kind == capi.CLOSEST else None, active, parked, n_active, owner_dev, world, rec, slot, leaf,
+                                     stream=self.stream.cuda_stream)
+        k = int(counts.sum())
+        return counts, rec[:k], slot[:k], leaf[:k]
+
+    def trace_records(self, kind, records):
+        k = int(records.shape[0])
+        res = torch.empty((k, 4 if kind == capi.CLOSEST else 1), dtype=torch.float32, device=self.device)
+        self.ctx.trace_leaf_records(kind, self.tri_mode, records.contiguous(), k, res, stream=self.stream.cuda_stream)
+        return res
+
+    def merge(self, kind, results, slot, leaf, st):
+        self.ctx.route_merge(kind, results.contiguous(), slot, leaf, int(slot.shape[0]), st if kind == capi.CLOSEST else None, st.get("hit"),
+                             stream=self.stream.cuda_stream)
+
     def finish(self):
         self.ctx.sync(self.stream.cuda_stream)
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
@@ -134,8 +158,29 @@ def _trace_sharded(engine, rays: torch.Tensor, owner_of_leaf, kind: int = capi.C
     st = engine.init_state(rays, kind)
     active = torch.arange(n, dtype=torch.int32, device=dev)
     rounds = leaf_visits = routed = 0
+    fast = bool(getattr(engine, "device_records", False))
+    owner_dev = owner.to(torch.int32).contiguous() if fast else None
+    cdev = "cpu" if (staging_cpu or dev.type == "cpu") else dev
     while True:
         parked = engine.top_episode(kind, rays, active, st) if active.numel() else torch.empty(0, dtype=torch.int32, device=dev)
+        if fast:
+            # everything between the all-to-alls stays in the library's kernels; the host only sees the per-rank counts
+            counts, rec, slots, leaves = engine.pack(kind, rays, active, parked, st, owner_dev, world)
+            total = torch.tensor([int(counts.sum())], dtype=torch.int64, device=cdev)
+            if world > 1:
+                dist.all_reduce(total)
+            if int(total.item()) == 0:
+                break
+            rounds += 1
+            leaf_visits += int(counts.sum())
+            routed += int(counts.sum() - counts[rank])
+            send_counts = torch.from_numpy(counts.astype(np.int64)).to(cdev)
+            got, recv_counts = _all_to_all_rows(rec, send_counts, staging_cpu)
+            res = engine.trace_records(kind, got)
+            back, _ = _all_to_all_rows(res, recv_counts, staging_cpu)
+            engine.merge(kind, back, slots, leaves, st)
+            active = slots
+            continue
         keep = parked != -1  # int32 view of MISS
         slots = active[keep].long()      # home ray ids that parked
         leaves = parked[keep].long().clamp_(0, owner.numel() - 1)  # (a corrupt id must not become a wild gather)

@@ -15,7 +15,7 @@ from pandora_amd import sharded  # noqa: E402
 
 
 def main():
-    out_dir, kind = sys.argv[1], int(sys.argv[2])
+    out_dir, kind, device_records = sys.argv[1], int(sys.argv[2]), bool(int(sys.argv[3]))
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -27,7 +27,7 @@ def main():
         ctx = pa.accel.Context(0)
         tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
         rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
-        eng = sharded.GpuEngine(ctx, dev)
+        eng = sharded.GpuEngine(ctx, dev, device_records=device_records)
         st, info = sharded.trace_sharded(eng, torch.from_numpy(np.ascontiguousarray(rays)).to(dev), owner, kind)
         cnt = ctx.counters()
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), routed=info["routed"], rounds=info["rounds"], leaf_visits=info["leaf_visits"],

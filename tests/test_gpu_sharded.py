@@ -41,15 +41,16 @@ def scene():
     ctx.close()
 
 
+@pytest.mark.parametrize("device_records", [True, False], ids=["device_records", "torch_records"])
 @pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
-def test_single_process_blocks_equal_pgpu_trace(scene, kind):
+def test_single_process_blocks_equal_pgpu_trace(scene, kind, device_records):
     import torch
     ctx, mesh, tl = scene
     rays = _rays(mesh)
     want, wcnt = ctx.trace(rays, kind=kind)
     dev = torch.device("cuda", 0)
     before = ctx.counters()
-    st, info = sharded.trace_sharded(sharded.GpuEngine(ctx, dev), torch.from_numpy(rays).to(dev), np.zeros(tl.n_leaves, np.int64), kind)
+    st, info = sharded.trace_sharded(sharded.GpuEngine(ctx, dev, device_records=device_records), torch.from_numpy(rays).to(dev), np.zeros(tl.n_leaves, np.int64), kind)
     after = ctx.counters()
     keys = ("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")
     for k in keys:
@@ -75,8 +76,9 @@ def test_trace_rejects_non_resident_leaves():
     ctx.close()
 
 
+@pytest.mark.parametrize("device_records", [1, 0], ids=["device_records", "torch_records"])
 @pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
-def test_two_processes_sharded_leaves(scene, kind):
+def test_two_processes_sharded_leaves(scene, kind, device_records):
     ctx, mesh, tl = scene
     rays = _rays(mesh)
     want, wcnt = ctx.trace(rays, kind=kind)
@@ -88,7 +90,7 @@ def test_two_processes_sharded_leaves(scene, kind):
         procs = []
         for r in range(2):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(kind)], env=env,
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(kind), str(device_records)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
