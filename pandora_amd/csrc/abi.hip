@@ -447,7 +447,7 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: closest-hit needs t, obj, leaf, u, v arrays");
     if (kind == PGPU_ANY && !any_hit)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: any-hit needs the any_hit array");
-    if (n > 0xFFFFFFF0ull)
+    if (n > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: batch too large");
     const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, rays->tfar };
     for (const float* p : rp)

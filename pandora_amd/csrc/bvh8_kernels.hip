@@ -6,14 +6,15 @@
 //   projects/pandora/src/shapes/triangle_intersect.cpp:425-462 (Moller-Trumbore, the compiled branch)
 //   and :340-423 (watertight variant, selectable).
 //
-// Mapping. The reference runs one ray at a time with the 8 children of a node in the 8 lanes of a
-// ymm register. Here a wave64 carries 8 rays; the 8 lanes of a "ray group" play the role of the 8
-// AVX2 lanes. Per step every group pops one stack entry and the wave issues two LDS-DMA loads
-// (global_load_lds_dwordx4) that bring the 8 x 256-byte nodes -- or the <=4 x 48-byte leaf triangles
-// -- of its 8 rays into LDS, 16 cache lines per wave step instead of 64 for per-lane gathers.
-// Child ordering is the node's precomputed octant permutation applied with ds_bpermute, hits are
-// compacted with a wave ballot + popcount prefix and pushed to a per-ray 96-entry stack in LDS.
-// Waves are persistent: they draw chunks of rays from a global cursor until it runs out.
+// Mapping. The reference runs one ray at a time with the 8 children of a node in the 8 lanes of a ymm register.
+// Here a wave64 carries 16 rays, one per quad of lanes: lane q owns children 2q and 2q+1 of the node its ray
+// visits and triangle q of its leaf, and values move inside a quad with DPP quad_perm modifiers. Per step every
+// ray pops one stack entry and the wave issues four LDS-DMA loads (global_load_lds_dwordx4) that bring the
+// 16 x 256-byte nodes of its rays into LDS. Child ordering is the node's precomputed octant permutation applied
+// through an LDS slot table, kept children are ranked with a byte-packed quad sum and pushed to a per-ray stack in
+// LDS (a window; deeper entries spill to HBM). Leaf triangles are loaded straight into registers and tested in
+// batches (rays wait at a leaf until several of the wave do). Waves are persistent: they draw chunks of rays from
+// per-XCD cursors until the work list runs out. DESIGN.md 3.1 has the details and the measurements.
 //
 // The reference compacts its whole stack after every leaf hit (dist < tfar). Order is preserved by
 // that compaction, so culling lazily at pop time is equivalent: entries pushed before the last hit
@@ -45,36 +46,32 @@ struct TriHit {
     bool hit;
 };
 
-// triangle_intersect.cpp:425-462, operation order kept (glm::cross / glm::dot expansion)
+// triangle_intersect.cpp:425-462, operation order kept (glm::cross / glm::dot expansion). The reference leaves at the first
+// failed test; a wave leaves only when all its lanes do, so every lane computes everything and the four rejections (the same
+// comparisons, so NaNs fall through them exactly as in the reference) are combined at the end.
 __device__ __forceinline__ TriHit triMT(float ox, float oy, float oz, float dx, float dy, float dz, float tnear, float tfar,
     float4 a, float4 b, float4 c)
 {
-    TriHit r;
-    r.hit = false;
-    r.t = r.u = r.v = 0.0f;
     const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
     const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
     const float hx = dy * e2z - e2y * dz;
     const float hy = dz * e2x - e2z * dx;
     const float hz = dx * e2y - e2x * dy;
     const float det = (e1x * hx + e1y * hy) + e1z * hz;
-    if (det > -0.000001f && det < 0.000001f)
-        return r;
+    const bool rejectDet = det > -0.000001f && det < 0.000001f;
     const float f = 1.0f / det;
     const float sx = ox - a.x, sy = oy - a.y, sz = oz - a.z;
     const float u = f * ((sx * hx + sy * hy) + sz * hz);
-    if (u < 0.0f || u > 1.0f)
-        return r;
+    const bool rejectU = u < 0.0f || u > 1.0f;
     const float qx = sy * e1z - e1y * sz;
     const float qy = sz * e1x - e1z * sx;
     const float qz = sx * e1y - e1x * sy;
     const float v = f * ((dx * qx + dy * qy) + dz * qz);
-    if (v < 0.0f || u + v > 1.0f)
-        return r;
+    const bool rejectV = v < 0.0f || u + v > 1.0f;
     const float t = f * ((e2x * qx + e2y * qy) + e2z * qz);
-    if (t < tnear || t > tfar)
-        return r;
-    r.hit = true;
+    const bool rejectT = t < tnear || t > tfar;
+    TriHit r;
+    r.hit = !(rejectDet || rejectU || rejectV || rejectT);
     r.t = t;
     r.u = u;
     r.v = v;
@@ -154,6 +151,14 @@ constexpr uint64_t kQuadLane0 = 0x1111111111111111ull;
 constexpr uint64_t kQuadLane3 = 0x8888888888888888ull;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+// element `i` of a wave-uniform array through a 32-bit byte offset (batches are limited to 2^30 rays): one shift serves
+// all output arrays and the stores use the SGPR-base addressing form
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, uint32_t byteOffset)
+{
+    return *reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + byteOffset);
+}
 
 // value of lane `(lane & ~3) | perm[lane & 3]` (v_*_dpp quad_perm: folded into the consuming VALU instruction)
 template <int P0, int P1, int P2, int P3>
@@ -414,9 +419,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         if (leafPass) {
             const bool isLeaf = st == 2;
             const bool triLane = isLeaf && q <= ((handle >> 29) & 3u); // count - 1 = low two flag bits (:378-382)
-            TriHit th;
-            th.hit = false;
-            th.t = th.u = th.v = 0.0f;
+            // (t = +inf marks "no hit"; u, v and obj of such lanes are never selected)
+            float tHit = __builtin_inff(), uHit = 0.0f, vHit = 0.0f;
             uint32_t obj = 0;
             if (triLane) {
                 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -425,8 +429,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 const f4v r0 = t[0], r1 = t[1], r2 = t[2];
                 const float4 p0 = make_float4(r0.x, r0.y, r0.z, r0.w), p1 = make_float4(r1.x, r1.y, r1.z, r1.w), p2 = make_float4(r2.x, r2.y, r2.z, r2.w);
                 obj = __float_as_uint(r0.w);
-                th = TRI == PGPU_TRI_WATERTIGHT_ID ? triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2)
-                                                   : triMT(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2);
+                const TriHit th = TRI == PGPU_TRI_WATERTIGHT_ID ? triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2)
+                                                                : triMT(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2);
+                if (th.hit) {
+                    tHit = th.t;
+                    uHit = th.u;
+                    vHit = th.v;
+                }
                 if (STATS)
                     statTri += 1;
             }
@@ -435,12 +444,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             // The reference tests the leaf's objects in order, each seeing the tfar left by the previous
             // one and accepting t <= tfar (:272-280). The survivor of that sequence is the LAST object
             // whose t equals the minimum of the valid t's.
-            const float best = quadMin(th.hit ? th.t : __builtin_inff());
-            const uint32_t winners = quadOr(th.hit && th.t == best ? qbit : 0u);
+            const float best = quadMin(tHit);
+            const uint32_t winners = quadOr(tHit == best && tHit != __builtin_inff() ? qbit : 0u);
             const int srcAddr = int(quadLane0x4 + ((31u - uint32_t(__builtin_clz(winners | 1u))) << 2)); // (no winner: unused)
-            const float wt = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.t)));
-            const float wu = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.u)));
-            const float wv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(th.v)));
+            const float wt = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(tHit)));
+            const float wu = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(uHit)));
+            const float wv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(vHit)));
             const uint32_t wobj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, int(obj)));
             if (isLeaf) {
                 st = 1;
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                     if (ANY) {
                         // :193-196: first hit ends the ray
                         if (q == 0)
-                            a.any_out[rayId] = 1u;
+                            at32(a.any_out, rayId << 2) = 1u;
                         st = 0;
                         sp = 0;
                         shift = 0;
@@ -541,21 +550,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         // ------------------------------------------------------------ retire rays whose stack ran dry
         if (st == 1 && sp == 0) {
             if (q == 0) {
+                const uint32_t off = rayId << 2;
                 if (ANY) {
                     if (a.init_miss)
-                        a.any_out[rayId] = 0u;
+                        at32(a.any_out, off) = 0u;
                 } else {
-                    a.t_out[rayId] = tfar;
+                    at32(a.t_out, off) = tfar;
                     if (hitObj != PGPU_MISS_ID) {
-                        a.obj_out[rayId] = hitObj;
-                        a.leaf_out[rayId] = tag;
-                        a.u_out[rayId] = hitU;
-                        a.v_out[rayId] = hitV;
+                        at32(a.obj_out, off) = hitObj;
+                        at32(a.leaf_out, off) = tag;
+                        at32(a.u_out, off) = hitU;
+                        at32(a.v_out, off) = hitV;
                     } else if (a.init_miss) {
-                        a.obj_out[rayId] = PGPU_MISS_ID;
-                        a.leaf_out[rayId] = 0u;
-                        a.u_out[rayId] = 0.0f;
-                        a.v_out[rayId] = 0.0f;
+                        at32(a.obj_out, off) = PGPU_MISS_ID;
+                        at32(a.leaf_out, off) = 0u;
+                        at32(a.u_out, off) = 0.0f;
+                        at32(a.v_out, off) = 0.0f;
                     }
                 }
             }

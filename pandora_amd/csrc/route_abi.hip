@@ -56,7 +56,7 @@ int pgpu_route_pack(pgpu_ctx* c, const pgpu_rays* rays, const float* t_state, co
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_route_pack: no top-level structure uploaded");
     if (world == 0 || world > routeMaxRanks())
         return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: between 1 and 64 ranks");
-    if (n_active > 0xFFFFFFF0ull)
+    if (n_active > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: batch too large");
     std::memset(dest_counts_host, 0, world * sizeof(uint32_t));
     if (n_active == 0)
@@ -101,7 +101,7 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: kind must be PGPU_CLOSEST or PGPU_ANY");
     if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: unknown triangle test");
-    if (k > 0xFFFFFFF0ull)
+    if (k > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: batch too large");
     if (k == 0)
         return PGPU_OK;
@@ -203,7 +203,7 @@ int pgpu_route_merge(pgpu_ctx* c, int kind, const float* results, const uint32_t
         return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: closest-hit needs t, obj, leaf, u, v arrays");
     if (kind == PGPU_ANY && !any_hit)
         return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: any-hit needs the any_hit array");
-    if (k > 0xFFFFFFF0ull)
+    if (k > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_route_merge: batch too large");
     if (k == 0)
         return PGPU_OK;

@@ -264,7 +264,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace: closest-hit needs t, obj, leaf, u, v arrays");
     if (kind == PGPU_ANY && !any_hit)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace: any-hit needs the any_hit array");
-    if (n > 0xFFFFFFF0ull)
+    if (n > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace: batch too large");
     const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, rays->tfar };
     for (const float* p : rp)
@@ -562,7 +562,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
 
 int pgpu_ray_state_init(pgpu_ctx* c, size_t n, const float* tfar, uint32_t* node, uint64_t* stack, const pgpu_hits* hits, uint32_t* any_hit, void* stream_)
 {
-    if (!c || !node || !stack || n > 0xFFFFFFF0ull)
+    if (!c || !node || !stack || n > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_ray_state_init: null argument or batch too large");
     if (!c->haveTop)
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_ray_state_init: no top-level structure uploaded");
@@ -593,7 +593,7 @@ int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_
     for (const float* p : rp)
         if (!p)
             return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: null ray array");
-    if (n_active > 0xFFFFFFF0ull)
+    if (n_active > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: batch too large");
     if (n_active == 0)
         return PGPU_OK;
@@ -645,7 +645,7 @@ int pgpu_trace_leaves(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
     for (const float* p : rp)
         if (!p)
             return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: null ray array");
-    if (n_work > 0xFFFFFFF0ull)
+    if (n_work > 0x3FFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: batch too large");
     if (n_work == 0)
         return PGPU_OK;
