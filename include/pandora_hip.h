@@ -198,13 +198,16 @@ int pgpu_trace(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, size_t 
  *                      active = ray ids to advance (NULL: 0..n_active-1); parked_leaf[i] = batching point work item i
  *                      parked at, or PGPU_MISS. t_state = current ray.tfar per ray (closest hit); any_out = occlusion
  *                      flags (any hit; occluded rays are skipped). SVDAG counters accumulate in the context.
+ *                      may_park = 0 makes a ray that reaches a batching point leave instead of pausing: the reference's
+ *                      traversal does not terminate on every ray (deviation 4), so a loop passes 0 once
+ *                      it has run n_leaves rounds.
  * pgpu_trace_leaves:   the leaf tasks (offline_batching...h:179-205, :226-259) without the resume: work item i
  *                      sends ray work_ray[i] through the bottom-level BVH of batching point work_leaf[i], which must be
  *                      resident here. Closest hit: hits->t is read as the ray's tfar and, like obj/leaf/u/v, written
  *                      only when the leaf yields a closer hit. Any hit: any_hit[ray] = 1 on a hit. */
 int pgpu_ray_state_init(pgpu_ctx*, size_t n, const float* tfar, uint32_t* node, uint64_t* stack, const pgpu_hits* hits, uint32_t* any_hit, void* stream);
 int pgpu_top_episode(pgpu_ctx*, int kind, const pgpu_rays* rays, const uint32_t* active, size_t n_active, uint32_t* node, uint64_t* stack,
-    const float* t_state, uint32_t* visits, uint32_t* any_hit, uint32_t* parked_leaf, void* stream);
+    const float* t_state, uint32_t* visits, uint32_t* any_hit, uint32_t* parked_leaf, int may_park, void* stream);
 int pgpu_trace_leaves(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, const uint32_t* work_ray, const uint32_t* work_leaf,
     size_t n_work, const pgpu_hits* hits, uint32_t* any_hit, void* stream);
 

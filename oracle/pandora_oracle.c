@@ -470,7 +470,19 @@ int orc_svdag_intersect(const orc_svdag* dag, const orc_ray* ray, int L)
 
     uint32_t stack[CAST_STACK_DEPTH + 1];
     int hit = 0;
+    /* height of the DAG: all leaves of an SVO sit at the same depth, follow first children */
+    uint32_t levels = 1;
+    for (uint32_t at = dag->root; levels < CAST_STACK_DEPTH; levels++) {
+        const uint32_t dsc = dag->data[at];
+        if ((dag_valid(dsc) & ~dag_leaf(dsc) & 0xFFu) == 0)
+            break;
+        at = dag->data[at + 1];
+    }
+    const uint64_t trip_cap = (uint64_t)(16u * levels + 16u) << levels;
+    uint64_t trips = 0;
     while (scale < CAST_STACK_DEPTH) {
+        if (++trips > trip_cap)
+            return 1; /* no progress (NaN operands): give up, do not cull */
         float tCorner[4];
         for (int i = 0; i < L; i++)
             tCorner[i] = pos[i] * tCoef[i] - tBias[i]; /* :434 */
@@ -560,10 +572,22 @@ int orc_svdag_intersect(const orc_svdag* dag, const orc_ray* ray, int L)
 int orc_bvh4_step(const orc_scene* s, int any_hit, int svdag_lanes, const orc_ray* r,
     uint32_t* node_io, uint64_t* stack_io, uint32_t* leaf_out, orc_counters* c)
 {
+    return orc_bvh4_step_ex(s, any_hit, svdag_lanes, r, node_io, stack_io, leaf_out, c, 1);
+}
+
+int orc_bvh4_step_ex(const orc_scene* s, int any_hit, int svdag_lanes, const orc_ray* r,
+    uint32_t* node_io, uint64_t* stack_io, uint32_t* leaf_out, orc_counters* c, int may_park)
+{
+    const uint64_t step_cap = 8ull * ((uint64_t)s->n_nodes + s->n_leaves) + 64ull;
+    uint64_t steps = 0;
     const float ix = 1.0f / r->d[0], iy = 1.0f / r->d[1], iz = 1.0f / r->d[2]; /* :241 */
     uint32_t nodeHandle = *node_io;
     uint64_t stack = *stack_io;
     for (;;) {
+        if (++steps > step_cap) { /* non-terminating traversal (see the header): the ray leaves the top level */
+            stack = 0xFFFFFFFFFFFFFFFFull;
+            break;
+        }
         const orc_bvh4_node* n = &s->nodes[nodeHandle];
         const int bitPos = 4 * (int)N4_DEPTH(n);
         const uint64_t interest = (stack >> bitPos) & 0xFull;
@@ -613,6 +637,10 @@ int orc_bvh4_step(const orc_scene* s, int any_hit, int svdag_lanes, const orc_ra
                         }
                     }
                     if (!culled) {
+                        if (!may_park) {
+                            stack = 0xFFFFFFFFFFFFFFFFull;
+                            break;
+                        }
                         *node_io = nodeHandle;
                         *stack_io = stack;
                         *leaf_out = leaf;
@@ -642,7 +670,9 @@ int orc_scene_intersect(const orc_scene* s, int tri_mode, int svdag_lanes, orc_r
         h->leaf = 0;
         h->u = h->v = 0.0f;
     }
-    while (orc_bvh4_step(s, 0, svdag_lanes, r, &node, &stack, &leaf, c)) {
+    uint32_t parks = 0;
+    while (orc_bvh4_step_ex(s, 0, svdag_lanes, r, &node, &stack, &leaf, c, parks < s->n_leaves)) {
+        parks++;
         if (c)
             c->leaf_visits++;
         /* leaf task kernel, offline_batching...h:183-185: bottom level updates ray.tfar / si */
@@ -661,7 +691,9 @@ int orc_scene_intersect_any(const orc_scene* s, int tri_mode, int svdag_lanes, o
 {
     uint32_t node = s->root, leaf = 0;
     uint64_t stack = 0xFFFFFFFFFFFFFFFFull;
-    while (orc_bvh4_step(s, 1, svdag_lanes, r, &node, &stack, &leaf, c)) {
+    uint32_t parks = 0;
+    while (orc_bvh4_step_ex(s, 1, svdag_lanes, r, &node, &stack, &leaf, c, parks < s->n_leaves)) {
+        parks++;
         if (c)
             c->leaf_visits++;
         if (orc_bvh8_intersect_any(&s->leaves[leaf].bvh, tri_mode, r, c))

@@ -89,6 +89,7 @@ typedef struct {
     uint32_t root;
     const orc_leaf* leaves;
     uint32_t n_leaves;
+    uint32_t n_nodes; /* size of `nodes` (bounds the work of a terminating traversal, see orc_bvh4_step_ex) */
 } orc_scene;
 
 typedef struct {
@@ -120,7 +121,9 @@ unsigned orc_bvh8_inner(const orc_bvh8_node* n, const orc_ray* r, uint32_t out_c
 int orc_bvh8_intersect(const orc_bvh8* b, int tri_mode, orc_ray* r, orc_hit* h, orc_counters* c);
 int orc_bvh8_intersect_any(const orc_bvh8* b, int tri_mode, orc_ray* r, orc_counters* c);
 
-/* sparse_voxel_dag.cpp:350-567; lanes = 4 (faithful, incl. the lane-3 artefact) or 3 */
+/* sparse_voxel_dag.cpp:350-567; lanes = 4 (faithful, incl. the lane-3 artefact) or 3. Guard added on both sides (oracle
+ * and GPU): with NaN operands the reference's ADVANCE makes no progress and loops forever; after (16 levels + 16) << levels
+ * loop trips (levels = height of the DAG) the cast gives up and reports a hit (conservative: the ray is not culled). */
 int orc_svdag_intersect(const orc_svdag* d, const orc_ray* r, int lanes);
 
 /* pauseable_bvh4.h:225-355 driven to completion per ray: every pause is followed immediately by the
@@ -132,6 +135,14 @@ int orc_scene_intersect_any(const orc_scene* s, int tri_mode, int svdag_lanes, o
  * or exits (returns 0). Used to check the per-visit tokens the GPU emits. */
 int orc_bvh4_step(const orc_scene* s, int any_hit, int svdag_lanes, const orc_ray* r,
     uint32_t* node, uint64_t* stack, uint32_t* leaf, orc_counters* c);
+/* The same with the two guards this repository adds on BOTH sides (oracle and GPU) because the reference's loop does not
+ * terminate on some rays: when every candidate child has tmin = +inf, blend(FLT_MAX, tmin) + horizontalMinIndex
+ * (pauseable_bvh4.h:297-299) picks a child that is NOT a candidate and the XOR at :304 then SETS its stack bit. A
+ * terminating traversal enters a node at most 5 times, so an episode is cut after 8 (n_nodes + n_leaves) + 64 loop trips
+ * (the ray leaves the top level), and a ray pauses at most n_leaves times: with may_park = 0 a ray that reaches a
+ * batching point leaves instead of pausing (orc_scene_intersect* pass that once a ray has paused n_leaves times). */
+int orc_bvh4_step_ex(const orc_scene* s, int any_hit, int svdag_lanes, const orc_ray* r,
+    uint32_t* node, uint64_t* stack, uint32_t* leaf, orc_counters* c, int may_park);
 
 /* batch drivers (SoA rays [8][n]: ox,oy,oz,dx,dy,dz,tnear,tfar), n_threads >= 1 */
 void orc_bvh8_trace(const orc_bvh8* b, int any_hit, int tri_mode, const float* rays, size_t n,

@@ -326,10 +326,10 @@ class Context:
         _check(self._L.pgpu_ray_state_init(self._h, n, capi.ptr(tfar), capi.ptr(node), capi.ptr(stack), C.byref(h) if h is not None else None,
                                            capi.ptr(any_hit), stream), self._h)
 
-    def top_episode(self, kind: int, rays, active, n_active: int, node, stack, t_state, visits, any_hit, parked_leaf, stream: int = 0):
+    def top_episode(self, kind: int, rays, active, n_active: int, node, stack, t_state, visits, any_hit, parked_leaf, may_park: bool = True, stream: int = 0):
         r, _ = self._rays_struct(rays)
         _check(self._L.pgpu_top_episode(self._h, kind, C.byref(r), capi.ptr(active), n_active, capi.ptr(node), capi.ptr(stack), capi.ptr(t_state),
-                                        capi.ptr(visits), capi.ptr(any_hit), capi.ptr(parked_leaf), stream), self._h)
+                                        capi.ptr(visits), capi.ptr(any_hit), capi.ptr(parked_leaf), int(may_park), stream), self._h)
 
     def trace_leaves(self, kind: int, tri_mode: int, rays, work_ray, work_leaf, n_work: int, hits: dict | None, any_hit=None, stream: int = 0):
         r, _ = self._rays_struct(rays)

@@ -41,10 +41,23 @@ __host__ __device__ constexpr uint32_t stackStrideBytes(uint32_t entries) { retu
 __device__ __forceinline__ float min86(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float max86(float a, float b) { return a > b ? a : b; }
 
+// One triangle test, split the way the leaf loop needs it: `pass` = every rejection that does not involve the ray
+// interval; (ka, kb) = what the interval test compares (Moller-Trumbore: t itself; watertight: tScaled and det);
+// hit = pass and inside [tnear, tfar] for the tfar the ray had when the leaf was entered.
 struct TriHit {
     float t, u, v;
-    bool hit;
+    float ka, kb;
+    bool pass, hit;
 };
+
+// the interval rejection of the two tests, for an arbitrary far end (triangle_intersect.cpp:450 and :412-415)
+template <int TRI>
+__device__ __forceinline__ bool intervalReject(float ka, float kb, float tnear, float tfar)
+{
+    if (TRI == PGPU_TRI_WATERTIGHT_ID)
+        return (kb < 0.0f && (ka >= tnear * kb || ka < tfar * kb)) || (kb > 0.0f && (ka <= tnear * kb || ka > tfar * kb));
+    return ka < tnear || ka > tfar;
+}
 
 // triangle_intersect.cpp:425-462, operation order kept (glm::cross / glm::dot expansion). The reference leaves at the first
 // failed test; a wave leaves only when all its lanes do, so every lane computes everything and the four rejections (the same
@@ -69,9 +82,11 @@ __device__ __forceinline__ TriHit triMT(float ox, float oy, float oz, float dx, 
     const float v = f * ((dx * qx + dy * qy) + dz * qz);
     const bool rejectV = v < 0.0f || u + v > 1.0f;
     const float t = f * ((e2x * qx + e2y * qy) + e2z * qz);
-    const bool rejectT = t < tnear || t > tfar;
     TriHit r;
-    r.hit = !(rejectDet || rejectU || rejectV || rejectT);
+    r.pass = !(rejectDet || rejectU || rejectV);
+    r.ka = t;
+    r.kb = 0.0f;
+    r.hit = r.pass && !intervalReject<0>(t, 0.0f, tnear, tfar);
     r.t = t;
     r.u = u;
     r.v = v;
@@ -120,21 +135,18 @@ __device__ __forceinline__ TriHit triWatertight(float ox, float oy, float oz, fl
         const double p1typ0tx = (double)p1y * (double)p0x;
         e2 = (float)(p1typ0tx - p1txp0ty);
     }
-    if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f))
-        return r;
+    const bool rejectSign = (e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f);
     const float det = e0 + e1 + e2;
-    if (det == 0.0f)
-        return r;
+    const bool rejectDet = det == 0.0f;
     p0z *= Sz;
     p1z *= Sz;
     p2z *= Sz;
     const float tScaled = e0 * p0z + e1 * p1z + e2 * p2z;
-    if (det < 0.0f && (tScaled >= tnear * det || tScaled < tfar * det))
-        return r;
-    else if (det > 0.0f && (tScaled <= tnear * det || tScaled > tfar * det))
-        return r;
     const float invDet = 1.0f / det;
-    r.hit = true;
+    r.pass = !(rejectSign || rejectDet);
+    r.ka = tScaled;
+    r.kb = det;
+    r.hit = r.pass && !intervalReject<1>(tScaled, det, tnear, tfar);
     r.u = e0 * invDet;
     r.v = e1 * invDet;
     r.t = tScaled * invDet;
@@ -420,8 +432,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             const bool isLeaf = st == 2;
             const bool triLane = isLeaf && q <= ((handle >> 29) & 3u); // count - 1 = low two flag bits (:378-382)
             // (t = +inf marks "no hit"; u, v and obj of such lanes are never selected)
-            float tHit = __builtin_inff(), uHit = 0.0f, vHit = 0.0f;
-            uint32_t obj = 0;
+            float tHit = __builtin_inff(), uHit = 0.0f, vHit = 0.0f, tRaw = 0.0f, ka = 0.0f, kb = 0.0f;
+            uint32_t obj = 0, pass = 0;
             if (triLane) {
                 typedef float f4v __attribute__((ext_vector_type(4)));
                 typedef const __attribute__((address_space(1))) f4v* gf4;
@@ -431,23 +443,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 obj = __float_as_uint(r0.w);
                 const TriHit th = TRI == PGPU_TRI_WATERTIGHT_ID ? triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2)
                                                                 : triMT(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2);
-                if (th.hit) {
+                uHit = th.u;
+                vHit = th.v;
+                tRaw = th.t;
+                ka = th.ka;
+                kb = th.kb;
+                pass = th.pass ? 1u : 0u;
+                if (th.hit)
                     tHit = th.t;
-                    uHit = th.u;
-                    vHit = th.v;
-                }
                 if (STATS)
                     statTri += 1;
             }
             if (STATS)
                 statLeaf += (isLeaf && q == 0);
-            // The reference tests the leaf's objects in order, each seeing the tfar left by the previous
-            // one and accepting t <= tfar (:272-280). The survivor of that sequence is the LAST object
-            // whose t equals the minimum of the valid t's.
-            const float best = quadMin(tHit);
-            const uint32_t winners = quadOr(tHit == best && tHit != __builtin_inff() ? qbit : 0u);
+            // The reference tests the leaf's objects in order, each seeing the tfar left by the previous one
+            // (:272-280). With Moller-Trumbore and ordinary numbers a test accepts t <= tfar, so the survivor of
+            // that sequence is the LAST object whose t equals the minimum of the accepted t's: one quad reduction.
+            // A NaN t breaks that argument (every comparison with it is false: it is accepted, and so is whatever
+            // comes after it), and the watertight test compares tScaled against tfar * det, which is not the same
+            // as t <= tfar to the last bit: those cases replay the sequence over the quad's 4 lanes.
+            uint32_t winners;
+            float tWin = tHit;
+            if (TRI == PGPU_TRI_WATERTIGHT_ID || __ballot(pass != 0u && tRaw != tRaw) != 0) {
+                float cur = tfar;
+                uint32_t win = 0;
+#define PANDORA_LEAF_STEP(I)                                                                                         \
+    {                                                                                                                \
+        const float kaI = quadBcast<I>(ka), kbI = quadBcast<I>(kb), tI = quadBcast<I>(tRaw);                         \
+        const bool acc = quadPerm<I, I, I, I>(int(pass)) != 0 && !intervalReject<TRI>(kaI, kbI, tnear, cur);         \
+        cur = acc ? tI : cur;                                                                                        \
+        win = acc ? (1u << I) : win;                                                                                 \
+    }
+                PANDORA_LEAF_STEP(0)
+                PANDORA_LEAF_STEP(1)
+                PANDORA_LEAF_STEP(2)
+                PANDORA_LEAF_STEP(3)
+#undef PANDORA_LEAF_STEP
+                winners = win;
+                tWin = tRaw;
+            } else {
+                const float best = quadMin(tHit);
+                winners = quadOr(tHit == best && tHit != __builtin_inff() ? qbit : 0u);
+            }
             const int srcAddr = int(quadLane0x4 + ((31u - uint32_t(__builtin_clz(winners | 1u))) << 2)); // (no winner: unused)
-            const float wt = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(tHit)));
+            const float wt = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(tWin)));
             const float wu = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(uHit)));
             const float wv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(vHit)));
             const uint32_t wobj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, int(obj)));

@@ -60,6 +60,7 @@ struct SvdagDev {
     uint32_t root;
     float bmin[3];
     float invExtent;
+    uint32_t levels; // height of this DAG (bounds the loop trips of a cast that makes progress)
 };
 struct TopLeafDev {
     uint32_t bvh;
@@ -86,6 +87,11 @@ struct TopTraceArgs {
     uint32_t* visits;        // may be nullptr
     uint32_t* any_out;       // any-hit: 1 once occluded
     uint32_t* parked_leaf;   // per work item of this round: batching point it parked at, or PGPU_MISS_ID
+    // Termination guards (deviation 4): the reference's loop does not terminate on every ray -- when every
+    // candidate child has tmin = +inf, blend(FLT_MAX, tmin) + horizontalMinIndex (pauseable_bvh4.h:297-299) picks a child
+    // that is not a candidate and the XOR at :304 then sets its stack bit.
+    uint32_t step_cap; // loop trips per episode before the ray is made to leave the top level
+    uint32_t may_park; // 0: a ray that reaches a batching point leaves instead of pausing (it has paused n_leaves times)
     uint32_t* leaf_count;
     unsigned long long* counters; // [0] svdag tests, [1] svdag culled
 };

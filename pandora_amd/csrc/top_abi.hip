@@ -182,6 +182,7 @@ int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const
         for (int a = 0; a < 3; ++a)
             dev[d].bmin[a] = dags[d].bounds_min[a];
         dev[d].invExtent = dags[d].inv_extent;
+        dev[d].levels = height[dags[d].root];
     }
     uint32_t* dw = nullptr;
     SvdagDev* dd = nullptr;
@@ -379,6 +380,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ta.any_out = dAny;
     ta.parked_leaf = dParkedLeaf;
     ta.leaf_count = dLeafCount;
+    ta.step_cap = uint32_t(std::min<uint64_t>(0xFFFFFFF0ull, 8ull * (uint64_t(c->top.n_nodes) + c->top.n_leaves) + 64ull));
     ta.counters = dCounters;
 
     Bvh8TraceArgs ba {};
@@ -427,6 +429,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
         ta.active = active;
         ta.n_active = nActive;
+        ta.may_park = rounds < nl ? 1u : 0u; // a ray pauses at most once per batching point
         HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u)), stream));
         // The scan and the binning do not depend on the host knowing the count: queue them behind the traversal,
         // then fetch the number of parked rays (it sizes the bottom-level launch and ends the loop).
@@ -579,7 +582,7 @@ int pgpu_ray_state_init(pgpu_ctx* c, size_t n, const float* tfar, uint32_t* node
 }
 
 int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_t* active, size_t n_active, uint32_t* node, uint64_t* stack,
-    const float* t_state, uint32_t* visits, uint32_t* any_hit, uint32_t* parked_leaf, void* stream_)
+    const float* t_state, uint32_t* visits, uint32_t* any_hit, uint32_t* parked_leaf, int may_park, void* stream_)
 {
     if (!c || !rays || !node || !stack || !parked_leaf)
         return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: null argument");
@@ -619,6 +622,8 @@ int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_
     ta.parked_leaf = parked_leaf;
     ta.leaf_count = nullptr;
     ta.counters = c->topCounters;
+    ta.step_cap = uint32_t(std::min<uint64_t>(0xFFFFFFF0ull, 8ull * (uint64_t(c->top.n_nodes) + c->top.n_leaves) + 64ull));
+    ta.may_park = may_park ? 1u : 0u;
     const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(6, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
     const uint32_t blocks = std::max(1u, std::min(uint32_t(c->numCUs) * perCU, uint32_t((n_active + 255) / 256)));
     HIP_TRY(c, launchTopTraverse(ta, kind, blocks, stream));

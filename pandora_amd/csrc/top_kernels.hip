@@ -71,7 +71,12 @@ __device__ bool svdagHit(const uint32_t* __restrict__ words, const SvdagDev& dag
     }
     uint32_t parent = dag.root;
     int scale = kCastDepth - 1;
+    // with NaN operands an ADVANCE makes no progress: after this many trips give up and do not cull (deviation 4)
+    const uint32_t tripCap = (16u * dag.levels + 16u) << dag.levels;
+    uint32_t trips = 0;
     while (scale < kCastDepth) {
+        if (++trips > tripCap)
+            return true;
         float tCorner[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -219,7 +224,10 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
             const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // :241
             uint32_t node = a.node[ray];
             uint64_t stack = a.stack[ray];
+            uint32_t steps = 0;
             for (;;) {
+                if (++steps > a.step_cap)
+                    break; // non-terminating traversal (kernels.h): the ray leaves the top level
                 const float* nf = reinterpret_cast<const float*>(nodeBase + size_t(node) * kTopNodeBytes);
                 const uint32_t* nu = reinterpret_cast<const uint32_t*>(nf);
                 const uint32_t bits = nu[27];
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
                                 }
                             }
                             if (!culled) {
-                                parked = true;
+                                parked = a.may_park != 0u;
                                 leafId = leaf;
                                 break;
                             }

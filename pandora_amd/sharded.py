@@ -89,11 +89,11 @@ class GpuEngine:
             self.ctx.ray_state_init(None, st["node"], st["stack"], None, st["hit"], stream=self.stream.cuda_stream)
         return st
 
-    def top_episode(self, kind, rays, active, st):
+    def top_episode(self, kind, rays, active, st, may_park=True):
         n_active = int(active.shape[0])
         parked = torch.empty(n_active, dtype=torch.int32, device=self.device)
         self.ctx.top_episode(kind, rays, active, n_active, st["node"], st["stack"], st.get("t"), st["visits"], st.get("hit"), parked,
-                             stream=self.stream.cuda_stream)
+                             may_park=may_park, stream=self.stream.cuda_stream)
         return parked
 
     def trace_leaves(self, kind, rays, work_leaf):
@@ -162,7 +162,8 @@ def _trace_sharded(engine, rays: torch.Tensor, owner_of_leaf, kind: int = capi.C
     owner_dev = owner.to(torch.int32).contiguous() if fast else None
     cdev = "cpu" if (staging_cpu or dev.type == "cpu") else dev
     while True:
-        parked = engine.top_episode(kind, rays, active, st) if active.numel() else torch.empty(0, dtype=torch.int32, device=dev)
+        # (a ray pauses at most once per batching point: past that many rounds it may only leave, see pgpu_top_episode)
+        parked = engine.top_episode(kind, rays, active, st, rounds < owner.numel()) if active.numel() else torch.empty(0, dtype=torch.int32, device=dev)
         if fast:
             # everything between the all-to-alls stays in the library's kernels; the host only sees the per-rank counts
             counts, rec, slots, leaves = engine.pack(kind, rays, active, parked, st, owner_dev, world)

@@ -38,7 +38,7 @@ class Leaf(C.Structure):
 
 
 class Scene(C.Structure):
-    _fields_ = [("nodes", C.c_void_p), ("root", C.c_uint32), ("leaves", C.c_void_p), ("n_leaves", C.c_uint32)]
+    _fields_ = [("nodes", C.c_void_p), ("root", C.c_uint32), ("leaves", C.c_void_p), ("n_leaves", C.c_uint32), ("n_nodes", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -64,6 +64,7 @@ def oracle() -> C.CDLL:
         _orc = C.CDLL(ORACLE_SO)
         _orc.orc_svdag_intersect.argtypes = [C.POINTER(Svdag), C.POINTER(Ray), C.c_int]
         _orc.orc_bvh4_step.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.POINTER(Ray), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p]
+        _orc.orc_bvh4_step_ex.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.POINTER(Ray), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
         _orc.orc_tri_intersect.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _orc.orc_bvh8_inner.argtypes = [C.c_void_p, C.POINTER(Ray), C.c_void_p, C.c_void_p]
         _orc.orc_bvh8_inner.restype = C.c_uint
@@ -155,7 +156,7 @@ class OracleScene:
                 self.leaves[i].dag = Svdag(self.dag_words.ctypes.data, int(d["root"]), (C.c_float * 3)(*[float(x) for x in d["bounds_min"]]), float(d["inv_extent"]), 1)
             else:
                 self.leaves[i].dag = Svdag(0, 0, (C.c_float * 3)(0, 0, 0), 0.0, 0)
-        self.c = Scene(self.top_nodes.ctypes.data, int(root), C.cast(self.leaves, C.c_void_p), len(leaf_bvhs))
+        self.c = Scene(self.top_nodes.ctypes.data, int(root), C.cast(self.leaves, C.c_void_p), len(leaf_bvhs), int(self.top_nodes.shape[0]))
 
     def trace(self, rays: np.ndarray, any_hit=False, tri_mode=0, lanes=3, threads=1, use_ref=False):
         n = rays.shape[1]

@@ -35,7 +35,7 @@ class OracleEngine:
             st["hit"] = torch.zeros(n, dtype=torch.int32)
         return st
 
-    def top_episode(self, kind, rays, active, st):
+    def top_episode(self, kind, rays, active, st, may_park=True):
         r = rays.numpy()
         parked = torch.full((active.numel(),), -1, dtype=torch.int32)
         for i, ray in enumerate(active.tolist()):
@@ -46,7 +46,7 @@ class OracleEngine:
             node = C.c_uint32(int(st["node"][ray]) & 0xFFFFFFFF)
             stack = C.c_uint64(int(st["stack"][ray]) & 0xFFFFFFFFFFFFFFFF)
             leaf = C.c_uint32(0)
-            if self.L.orc_bvh4_step(C.byref(self.scene.c), kind, self.lanes, C.byref(cr), C.byref(node), C.byref(stack), C.byref(leaf), C.byref(self.counters)):
+            if self.L.orc_bvh4_step_ex(C.byref(self.scene.c), kind, self.lanes, C.byref(cr), C.byref(node), C.byref(stack), C.byref(leaf), C.byref(self.counters), int(may_park)):
                 st["node"][ray] = int(np.array(node.value, np.uint32).view(np.int32))
                 st["stack"][ray] = int(np.array(stack.value, np.uint64).view(np.int64))
                 st["visits"][ray] += 1
