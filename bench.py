@@ -100,15 +100,8 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        nn = torch.tensor([n], dtype=torch.int64, device=dev)
-        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
-        total_rays = int(nn.item())
-    else:
-        total_rays = n
+    from pandora_amd.sharded import reduce_job
+    elapsed, total_rays = reduce_job(elapsed, n, dev)  # max over ranks, rays summed over ranks
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps

@@ -42,6 +42,20 @@ def assign_leaves(weights, world: int) -> np.ndarray:
     return owner
 
 
+def reduce_job(elapsed_s: float, n_units: int, device=None):
+    """Whole-job figures of a run in which every rank processed its own units (rays) between two barriers:
+    (slowest rank's time, units summed over ranks). Works on any backend (nccl needs `device`)."""
+    rank, world = _world()
+    if world == 1:
+        return float(elapsed_s), int(n_units)
+    dev = device if device is not None else "cpu"
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n = torch.tensor([n_units], dtype=torch.int64, device=dev)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(n.item())
+
+
 def _world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 

@@ -69,3 +69,23 @@ def test_assign_leaves_balances_and_is_deterministic():
     loads = np.bincount(a, weights=w, minlength=3)
     assert loads.max() - loads.min() <= w.max()
     assert np.array_equal(sharded.assign_leaves(w, 1), np.zeros(w.size, np.int64))
+
+
+def _reduce_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        el, n = sharded.reduce_job(1.0 + rank, 1000 * (rank + 1))
+        np.save(os.path.join(out_dir, f"red{rank}.npy"), np.array([el, n]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_aggregation_world2():
+    """bench.py's whole-job figures: slowest rank's time, rays summed over ranks (every rank must see the same)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_reduce_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        for r in range(2):
+            el, n = np.load(os.path.join(d, f"red{r}.npy"))
+            assert el == 2.0 and n == 3000
+    assert sharded.reduce_job(0.5, 7) == (0.5, 7)  # no process group: identity
