@@ -236,11 +236,14 @@ int pgpu_sync(pgpu_ctx*, void* stream);
 int pgpu_set_stats(pgpu_ctx*, int enabled);
 int pgpu_get_counters(pgpu_ctx*, pgpu_counters* out);
 int pgpu_set_tuning(pgpu_ctx*, int blocks_per_cu, int chunk); /* blocks_per_cu 0 = automatic */
-/* Bottom-level kernel scheduling knobs: how many of a wave's 16 rays must have finished before new rays
- * are fetched, how many entries of each ray's traversal stack stay in LDS (0 = automatic; deeper entries
+/* Bottom-level kernel scheduling knobs: how many of a wave's rays must have finished before new rays
+ * are fetched (0 = automatic), how many entries of each ray's traversal stack stay in LDS (0 = automatic; deeper entries
  * spill to HBM), and how many rays of a wave must wait at a leaf before the wave runs its triangle code
  * (0 = automatic). Results do not depend on any of them. */
 int pgpu_set_kernel_variant(pgpu_ctx*, int refill_min, int stack_window, int leaf_min);
+/* Lanes of a wave64 that share one ray in the bottom-level kernel: 4 (16 rays per wave, node staged in LDS) or
+ * 2 (32 rays per wave, node halves in registers, two triangles per lane). Results do not depend on it. */
+int pgpu_set_ray_layout(pgpu_ctx*, int lanes_per_ray);
 
 #ifdef __cplusplus
 }

@@ -368,8 +368,12 @@ class Context:
     def set_tuning(self, blocks_per_cu: int, chunk: int):
         _check(self._L.pgpu_set_tuning(self._h, blocks_per_cu, chunk), self._h)
 
-    def set_kernel_variant(self, refill_min: int = 3, stack_window: int = 0, leaf_min: int = 0):
+    def set_kernel_variant(self, refill_min: int = 0, stack_window: int = 0, leaf_min: int = 0):
         _check(self._L.pgpu_set_kernel_variant(self._h, refill_min, stack_window, leaf_min), self._h)
+
+    def set_ray_layout(self, lanes_per_ray: int):
+        """4: quad kernel (16 rays per wave); 2: pair kernel (32 rays per wave)."""
+        _check(self._L.pgpu_set_ray_layout(self._h, lanes_per_ray), self._h)
 
     def counters(self) -> dict:
         cnt = capi.Counters()

@@ -101,6 +101,7 @@ SYMBOLS = {
     "pgpu_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "pgpu_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pgpu_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "pgpu_set_ray_layout": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

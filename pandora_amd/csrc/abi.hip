@@ -142,15 +142,17 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a,
 {
     const uint32_t need = stackEntriesForDepth(depth);
     const uint32_t window = stackWindow(need, c->stackWindow);
+    const uint32_t lanes = c->lanesPerRay;
+    a.lanes_per_ray = lanes;
     a.stack_entries = window;
-    a.refill_min = c->refillMin;
+    a.refill_min = c->refillMin ? c->refillMin : (lanes == 2u ? 6u : 3u);
     a.n_bvhs = uint32_t(c->bvhs.size());
     a.range_size = uint32_t((((n_work + 7) / 8 + a.chunk - 1) / a.chunk) * a.chunk);
-    a.leaf_min = c->leafMin ? c->leafMin : 4u;
+    a.leaf_min = c->leafMin ? c->leafMin : (lanes == 2u ? 8u : 4u);
     a.spill_entries = need > window ? need - window : 0u;
     a.spill = nullptr;
-    const uint32_t raysPerBlock = 64u; // 4 waves x 16 rays
-    const uint32_t maxBlocks = uint32_t(c->numCUs) * blocksPerCU(c->blocksPerCU, window);
+    const uint32_t raysPerBlock = 256u / lanes; // 4 waves x 16 (or 32) rays
+    const uint32_t maxBlocks = uint32_t(c->numCUs) * blocksPerCU(c->blocksPerCU, window, lanes);
     const uint32_t wantBlocks = uint32_t((n_work + 2 * raysPerBlock - 1) / (2 * raysPerBlock));
     *blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
     if (a.spill_entries) {
@@ -269,12 +271,20 @@ int pgpu_set_tuning(pgpu_ctx* c, int blocks_per_cu, int chunk)
 
 int pgpu_set_kernel_variant(pgpu_ctx* c, int refill_min, int stack_window, int leaf_min)
 {
-    if (!c || refill_min < 1 || refill_min > 16 || stack_window < 0 || stack_window > 96
-        || leaf_min < 0 || leaf_min > 16)
+    if (!c || refill_min < 0 || refill_min > 32 || stack_window < 0 || stack_window > 96
+        || leaf_min < 0 || leaf_min > 32)
         return PGPU_ERR_INVALID;
     c->leafMin = uint32_t(leaf_min);
     c->refillMin = uint32_t(refill_min);
     c->stackWindow = stack_window;
+    return PGPU_OK;
+}
+
+int pgpu_set_ray_layout(pgpu_ctx* c, int lanes_per_ray)
+{
+    if (!c || (lanes_per_ray != 2 && lanes_per_ray != 4))
+        return PGPU_ERR_INVALID;
+    c->lanesPerRay = uint32_t(lanes_per_ray);
     return PGPU_OK;
 }
 
@@ -319,7 +329,7 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
         return bad(PGPU_ERR_INVALID, "malformed tree (handle out of range or cycle)");
     if (7 * depth + 8 > 96) // the 96-entry traversal stack of wive_bvh8_impl.h:74-75
         return bad(PGPU_ERR_DEPTH, "more than 12 nested inner nodes");
-    tris.assign(n_indices * 12, 0.0f);
+    tris.assign((n_indices + 1) * 12, 0.0f); // (one zero record of padding: the pair kernel reads records two at a time)
     for (size_t s = 0; s < n_indices; ++s) {
         const uint32_t obj = leaf_indices[s];
         if (obj >= n_objs)

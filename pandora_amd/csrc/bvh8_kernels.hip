@@ -628,19 +628,501 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Pair layout: a wave64 carries 32 rays, one per pair of lanes. Lane p of a pair owns children 4p..4p+3 of the node
+// its ray visits (loaded straight into registers: 8 x 16 bytes) and triangles 2p, 2p+1 of its leaf (two triangles
+// per lane run through the packed-FP32 pipe together). The per-ray bookkeeping (pop, state, ranking, retire) is the
+// same number of instructions as in the quad layout but serves twice as many rays. LDS holds only the 8 order slots
+// and the stack window of every ray.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kPairRaysPerWave = 32;
+constexpr uint32_t kPairSlotBytes = 80; // 8 x (child, tmin) + 16 bytes that spread the rays over the banks
+constexpr uint64_t kPairLane0 = 0x5555555555555555ull;
+constexpr uint64_t kPairLane1 = 0xAAAAAAAAAAAAAAAAull;
+
+__device__ __forceinline__ int pairSwap(int v) { return quadPerm<1, 0, 3, 2>(v); }
+__device__ __forceinline__ uint32_t pairOr(uint32_t v) { return v | uint32_t(pairSwap(int(v))); }
+template <int L>
+__device__ __forceinline__ float pairBcastF(float v) { return __int_as_float(quadPerm<L, L, 2 + L, 2 + L>(__float_as_int(v))); }
+template <int L>
+__device__ __forceinline__ int pairBcastI(int v) { return quadPerm<L, L, 2 + L, 2 + L>(v); }
+
+__device__ __forceinline__ f2 mk2(float x, float y)
+{
+    f2 r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f2 half2of(f4v_t v, int h) { return h ? __builtin_shufflevector(v, v, 2, 3) : __builtin_shufflevector(v, v, 0, 1); }
+
+struct TriHit2 {
+    f2 t, u, v, ka, kb;
+    bool pass[2], hit[2];
+};
+
+// triMT for two triangles at once (component i of every f2 belongs to triangle i): the same operations in the same
+// order, issued as packed FP32 where the hardware has them (add, mul).
+__device__ __forceinline__ TriHit2 triMT2(float ox, float oy, float oz, float dx, float dy, float dz, float tnear, float tfar,
+    f2 ax, f2 ay, f2 az, f2 bx, f2 by, f2 bz, f2 cx, f2 cy, f2 cz)
+{
+    const f2 e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    const f2 e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    const f2 hx = dy * e2z - e2y * dz;
+    const f2 hy = dz * e2x - e2z * dx;
+    const f2 hz = dx * e2y - e2x * dy;
+    const f2 det = (e1x * hx + e1y * hy) + e1z * hz;
+    f2 f;
+    f.x = 1.0f / det.x;
+    f.y = 1.0f / det.y;
+    const f2 sx = ox - ax, sy = oy - ay, sz = oz - az;
+    const f2 u = f * ((sx * hx + sy * hy) + sz * hz);
+    const f2 qx = sy * e1z - e1y * sz;
+    const f2 qy = sz * e1x - e1z * sx;
+    const f2 qz = sx * e1y - e1x * sy;
+    const f2 v = f * ((dx * qx + dy * qy) + dz * qz);
+    const f2 t = f * ((e2x * qx + e2y * qy) + e2z * qz);
+    const f2 uv = u + v;
+    TriHit2 r;
+    r.pass[0] = !((det.x > -0.000001f && det.x < 0.000001f) || (u.x < 0.0f || u.x > 1.0f) || (v.x < 0.0f || uv.x > 1.0f));
+    r.pass[1] = !((det.y > -0.000001f && det.y < 0.000001f) || (u.y < 0.0f || u.y > 1.0f) || (v.y < 0.0f || uv.y > 1.0f));
+    r.hit[0] = r.pass[0] && !intervalReject<0>(t.x, 0.0f, tnear, tfar);
+    r.hit[1] = r.pass[1] && !intervalReject<0>(t.y, 0.0f, tnear, tfar);
+    r.t = t;
+    r.u = u;
+    r.v = v;
+    r.ka = t;
+    r.kb = mk2(0.0f, 0.0f);
+    return r;
+}
+
+template <bool ANY, int TRI, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void bvh8TracePairKernel(Bvh8TraceArgs a)
+{
+    extern __shared__ __align__(16) unsigned char ldsGeneric[];
+    lds_u8* const lds = (lds_u8*)ldsGeneric;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+    const uint32_t r = lane >> 1, p = lane & 1u;
+    const uint32_t W = a.stack_entries;
+
+    // LDS: [4 waves x 32 rays x order slots][4 waves x 32 rays x stack window]
+    lds_u8* const slotBase = lds + (wave * kPairRaysPerWave + r) * kPairSlotBytes;
+    lds_u8* const stackBase = lds + kWavesPerBlock * kPairRaysPerWave * kPairSlotBytes + (wave * kPairRaysPerWave + r) * stackStrideBytes(W);
+    unsigned long long* const spill = a.spill ? a.spill + (size_t(blockIdx.x * kWavesPerBlock + wave) * kPairRaysPerWave + r) * a.spill_entries : nullptr;
+    const uint32_t pairLane0x4 = (lane & ~1u) << 2;
+    const uint32_t belowMask = p ? 0xFFFFFFFFu : 0u;
+
+    auto stackStore = [&](uint32_t idx, uint2 v) {
+        if (idx < W) {
+            ldsStoreU2(stackBase + idx * 8u, v);
+        } else {
+            __hip_atomic_store(&spill[idx - W], (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    auto stackLoad = [&](uint32_t idx) {
+        if (idx < W)
+            return ldsU2(stackBase + idx * 8u);
+        const unsigned long long v = __hip_atomic_load(&spill[idx - W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2(uint32_t(v), uint32_t(v >> 32));
+    };
+
+    // per-ray state, replicated over the 2 lanes of the pair
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
+    float hitU = 0, hitV = 0;
+    uint32_t hitObj = PGPU_MISS_ID, rayId = 0, tag = 0, handle = 0;
+    uint32_t shift = 0; // bits 4:0 octant bit offset, bit 8 exact slab test (as in the quad kernel)
+    const unsigned char* nodesP = nullptr; // nodes + p * 16: this lane's half of every 32-byte array
+    const unsigned char* trisP = nullptr;  // tris + p * 96: triangles 2p, 2p+1 of leaf slot 0
+    // byte offset of the near-side plane array per axis (min array if 1/d >= 0 else max array); the far one is 32 bytes
+    // away (offset ^ 32)
+    uint32_t offNX = 0, offNY = 64, offNZ = 128;
+    int sp = 0, hitMark = 0;
+    int st = 0; // 0 idle, 1 traversing, 2 waiting at a popped leaf, 3 popped an inner node (inside one step)
+    uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
+    uint32_t range = blockIdx.x & 7u;
+    bool exhausted = false;
+    uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
+
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) f4v* gf4;
+    typedef const __attribute__((address_space(1))) u4v* gu4;
+
+    for (bool done = false; !done;) {
+        // ------------------------------------------------------------ refill idle pairs
+        const uint64_t idleMask = __ballot(st == 0);
+        const uint32_t nIdle = uint32_t(__popcll(idleMask & kPairLane0));
+        uint64_t liveMask = ~idleMask;
+        if (!exhausted && (nIdle >= a.refill_min || nIdle == kPairRaysPerWave)) {
+            for (uint32_t tried = 0; chunkNext >= chunkEnd && !exhausted;) {
+                uint32_t c = 0;
+                if (lane == 0)
+                    c = atomicAdd(a.cursor + range * 8u, a.chunk);
+                c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
+                const uint32_t lo = range * a.range_size, hi = min(lo + a.range_size, a.n_work);
+                if (lo < hi && c < hi - lo) {
+                    chunkNext = lo + c;
+                    chunkEnd = min(chunkNext + a.chunk, hi);
+                } else if (++tried == 8u) {
+                    exhausted = true;
+                } else {
+                    range = (range + 1u) & 7u;
+                }
+            }
+            const uint64_t marks = idleMask & kPairLane1; // (the marker sits in lane 1 so that a pair does not count itself)
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(marks >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(marks), 0u));
+            const uint32_t w = chunkNext + rank;
+            const bool take = st == 0 && w < chunkEnd;
+            chunkNext = uint32_t(__builtin_amdgcn_readfirstlane(int(min(chunkNext + nIdle, chunkEnd))));
+            liveMask |= __ballot(take);
+            if (take) {
+                rayId = a.work_ray ? a.work_ray[w] : w;
+                const uint32_t bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
+                tag = a.work_tag ? a.work_tag[w] : 0u;
+                const Bvh8Dev bd = a.bvhs[min(bvhId, a.n_bvhs - 1u)];
+                nodesP = bd.nodes + p * 16u;
+                trisP = bd.tris + p * 96u;
+                ox = a.ox[rayId];
+                oy = a.oy[rayId];
+                oz = a.oz[rayId];
+                dx = a.dx[rayId];
+                dy = a.dy[rayId];
+                dz = a.dz[rayId];
+                tnear = a.tnear[rayId];
+                tfar = a.tfar_in[rayId];
+                ix = 1.0f / dx; // wive_bvh8_impl.h:66-68: no zero guard
+                iy = 1.0f / dy;
+                iz = 1.0f / dz;
+                // rays that can meet 0 * inf (or carry inf/NaN themselves) take the x86-exact slab test
+                const float big = 3.4028234663852886e38f;
+                const bool tame = fabsf(ix) <= big && ix != 0.0f && fabsf(ox) <= big && fabsf(iy) <= big && iy != 0.0f && fabsf(oy) <= big
+                    && fabsf(iz) <= big && iz != 0.0f && fabsf(oz) <= big && tnear == tnear && tfar == tfar;
+                shift = ((dx > 0.0f ? 1u : 0u) | (dy > 0.0f ? 2u : 0u) | (dz > 0.0f ? 4u : 0u)) * 3u; // :384-388
+                shift |= ((tame ? 0u : 1u) | (bd.needs_exact != 0u ? 1u : 0u)) << 8;
+                offNX = ix < 0.0f ? 32u : 0u;
+                offNY = iy < 0.0f ? 96u : 64u;
+                offNZ = iz < 0.0f ? 160u : 128u;
+                hitObj = PGPU_MISS_ID;
+                hitU = hitV = 0.0f;
+                if (p == 0)
+                    ldsStoreU2(stackBase, make_uint2(bd.root, __float_as_uint(0.0f))); // :80-82
+                sp = 1;
+                hitMark = 0;
+                st = (bvhId < a.n_bvhs && bd.nodes != nullptr) ? 1 : 0;
+            }
+            if (STATS)
+                statRefill += (lane == 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (liveMask == 0) {
+            done = exhausted;
+        } else {
+        // ------------------------------------------------------------ pop: the top 4 entries at once (2 per lane)
+        {
+            const bool run = st == 1;
+            const int top = sp - 1;
+            const int e0 = top - 2 * int(p), e1 = e0 - 1;
+            const bool valid0 = run && e0 >= 0, valid1 = run && e1 >= 0;
+            const bool deep = __ballot(uint32_t(sp) > W) != 0;
+            uint2 ent0 = make_uint2(0u, 0u), ent1 = make_uint2(0u, 0u);
+            if (valid0) {
+                if (!deep) {
+                    ent0 = ldsU2(stackBase + uint32_t(e0) * 8u);
+                    ent1 = ldsU2(stackBase + uint32_t(max(e1, 0)) * 8u);
+                } else {
+                    ent0 = stackLoad(uint32_t(e0));
+                    ent1 = stackLoad(uint32_t(max(e1, 0)));
+                }
+            }
+            const bool ok0 = valid0 && (e0 >= hitMark || __uint_as_float(ent0.y) < tfar);
+            const bool ok1 = valid1 && (e1 >= hitMark || __uint_as_float(ent1.y) < tfar);
+            const uint32_t m = pairOr(((ok0 ? 1u : 0u) | (ok1 ? 2u : 0u)) << (2u * p));
+            const uint32_t first = uint32_t(__builtin_ctz(m | 16u));
+            const uint32_t cand = (first & 1u) ? ent1.x : ent0.x;
+            const uint32_t popped = uint32_t(__builtin_amdgcn_ds_bpermute(int(pairLane0x4 + ((first >> 1) << 2)), int(cand)));
+            const bool got = run && m != 0u;
+            sp = run ? (m != 0u ? top - int(first) : max(sp - 4, 0)) : sp;
+            hitMark = min(hitMark, sp);
+            handle = got ? popped : handle;
+            st = got ? ((popped >> 29) == 2u ? 3 : 2) : st;
+        }
+        const uint64_t pendMask = __ballot(st == 2);
+        const uint64_t innerMask = __ballot(st == 3);
+        const uint32_t leafPassU = uint32_t(pendMask != 0) & (uint32_t(uint32_t(__popcll(pendMask & kPairLane0)) >= a.leaf_min) | uint32_t(innerMask == 0));
+        const bool leafPass = leafPassU != 0u;
+        const uint32_t index = handle & 0x1FFFFFFFu;
+        if (STATS) {
+            statIter += (lane == 0);
+            statLeafPass += (lane == 0 && leafPass);
+        }
+
+        // ------------------------------------------------------------ fetch: this lane's half of the node -> registers
+        // (deliberately not initialised: the lanes that do not load do not use them either, and zeroing 32 registers
+        // per step costs more than the slab test)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wuninitialized"
+        f4v nearX, farX, nearY, farY, nearZ, farZ;
+        u4v child4, perm4;
+        if (st == 3) {
+            const unsigned char* nb = nodesP + size_t(index) * 256u;
+            nearX = *(gf4)(nb + offNX);
+            farX = *(gf4)(nb + (offNX ^ 32u));
+            nearY = *(gf4)(nb + offNY);
+            farY = *(gf4)(nb + (offNY ^ 32u));
+            nearZ = *(gf4)(nb + offNZ);
+            farZ = *(gf4)(nb + (offNZ ^ 32u));
+            child4 = *(gu4)(nb + 192);
+            perm4 = *(gu4)(nb + 224);
+        }
+#pragma clang diagnostic pop
+
+        // ------------------------------------------------------------ leaf pass: <= 4 triangles, two per lane
+        if (leafPass) {
+            const bool isLeaf = st == 2;
+            const uint32_t last = (handle >> 29) & 3u; // count - 1 (:378-382)
+            const bool tri0 = isLeaf && 2u * p <= last, tri1 = isLeaf && 2u * p + 1u <= last;
+            f2 tHit = mk2(__builtin_inff(), __builtin_inff()), uHit = mk2(0.0f, 0.0f), vHit = mk2(0.0f, 0.0f), tRaw = mk2(0.0f, 0.0f), ka = mk2(0.0f, 0.0f), kb = mk2(0.0f, 0.0f);
+            uint32_t obj0 = 0, obj1 = 0, pass0 = 0, pass1 = 0;
+            if (tri0) {
+                gf4 t = (gf4)(trisP + size_t(index) * 48u);
+                // (the record after the leaf's last one exists: the array ends in a zero record)
+                const f4v a0 = t[0], a1 = t[1], a2 = t[2], b0 = t[3], b1 = t[4], b2 = t[5];
+                obj0 = __float_as_uint(a0.w);
+                obj1 = __float_as_uint(b0.w);
+                if (TRI == PGPU_TRI_WATERTIGHT_ID) {
+                    const TriHit h0 = triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, make_float4(a0.x, a0.y, a0.z, 0.0f),
+                        make_float4(a1.x, a1.y, a1.z, 0.0f), make_float4(a2.x, a2.y, a2.z, 0.0f));
+                    const TriHit h1 = triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, make_float4(b0.x, b0.y, b0.z, 0.0f),
+                        make_float4(b1.x, b1.y, b1.z, 0.0f), make_float4(b2.x, b2.y, b2.z, 0.0f));
+                    uHit = mk2(h0.u, h1.u);
+                    vHit = mk2(h0.v, h1.v);
+                    tRaw = mk2(h0.t, h1.t);
+                    ka = mk2(h0.ka, h1.ka);
+                    kb = mk2(h0.kb, h1.kb);
+                    pass0 = h0.pass ? 1u : 0u;
+                    pass1 = (h1.pass && tri1) ? 1u : 0u;
+                    if (h0.hit)
+                        tHit.x = h0.t;
+                    if (h1.hit && tri1)
+                        tHit.y = h1.t;
+                } else {
+                    const TriHit2 th = triMT2(ox, oy, oz, dx, dy, dz, tnear, tfar, mk2(a0.x, b0.x), mk2(a0.y, b0.y), mk2(a0.z, b0.z),
+                        mk2(a1.x, b1.x), mk2(a1.y, b1.y), mk2(a1.z, b1.z), mk2(a2.x, b2.x), mk2(a2.y, b2.y), mk2(a2.z, b2.z));
+                    uHit = th.u;
+                    vHit = th.v;
+                    tRaw = th.t;
+                    ka = th.ka;
+                    kb = th.kb;
+                    pass0 = th.pass[0] ? 1u : 0u;
+                    pass1 = (th.pass[1] && tri1) ? 1u : 0u;
+                    if (th.hit[0])
+                        tHit.x = th.t.x;
+                    if (th.hit[1] && tri1)
+                        tHit.y = th.t.y;
+                }
+                if (STATS)
+                    statTri += 1u + (tri1 ? 1u : 0u);
+            }
+            if (STATS)
+                statLeaf += (isLeaf && p == 0);
+            // (see the quad kernel for why the fast path is "last object whose t equals the minimum" and when the
+            // sequence has to be replayed)
+            uint32_t winners;
+            f2 tWin = tHit;
+            if (TRI == PGPU_TRI_WATERTIGHT_ID || __ballot((pass0 != 0u && tRaw.x != tRaw.x) || (pass1 != 0u && tRaw.y != tRaw.y)) != 0) {
+                float cur = tfar;
+                uint32_t win = 0;
+#define PANDORA_LEAF_STEP2(L, C, PASS, BIT)                                                                          \
+    {                                                                                                                \
+        const float kaI = pairBcastF<L>(ka.C), kbI = pairBcastF<L>(kb.C), tI = pairBcastF<L>(tRaw.C);                \
+        const bool acc = pairBcastI<L>(int(PASS)) != 0 && !intervalReject<TRI>(kaI, kbI, tnear, cur);                \
+        cur = acc ? tI : cur;                                                                                        \
+        win = acc ? (1u << BIT) : win;                                                                               \
+    }
+                PANDORA_LEAF_STEP2(0, x, pass0, 0)
+                PANDORA_LEAF_STEP2(0, y, pass1, 1)
+                PANDORA_LEAF_STEP2(1, x, pass0, 2)
+                PANDORA_LEAF_STEP2(1, y, pass1, 3)
+#undef PANDORA_LEAF_STEP2
+                winners = win;
+                tWin = tRaw;
+            } else {
+                const float bestLocal = fminf(tHit.x, tHit.y);
+                const float best = fminf(bestLocal, __int_as_float(pairSwap(__float_as_int(bestLocal))));
+                const uint32_t mine = ((tHit.x == best ? 1u : 0u) | (tHit.y == best ? 2u : 0u)) << (2u * p);
+                winners = best != __builtin_inff() ? pairOr(mine) : 0u;
+            }
+            const uint32_t widx = 31u - uint32_t(__builtin_clz(winners | 1u)); // (no winner: unused)
+            const bool second = (widx & 1u) != 0u;
+            const int srcAddr = int(pairLane0x4 + ((widx >> 1) << 2));
+            const float wt = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(second ? tWin.y : tWin.x)));
+            const float wu = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(second ? uHit.y : uHit.x)));
+            const float wv = __int_as_float(__builtin_amdgcn_ds_bpermute(srcAddr, __float_as_int(second ? vHit.y : vHit.x)));
+            const uint32_t wobj = uint32_t(__builtin_amdgcn_ds_bpermute(srcAddr, int(second ? obj1 : obj0)));
+            if (isLeaf) {
+                st = 1;
+                if ((winners & 0xFu) != 0u) {
+                    if (ANY) {
+                        if (p == 0)
+                            at32(a.any_out, rayId << 2) = 1u; // :193-196: first hit ends the ray
+                        st = 0;
+                        sp = 0;
+                        shift = 0;
+                    } else {
+                        tfar = wt;
+                        hitU = wu;
+                        hitV = wv;
+                        hitObj = wobj;
+                        hitMark = sp; // everything still on the stack predates this hit
+                    }
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ inner node: slab test of this lane's four children
+        if (st == 3) {
+            float tmin[4], tmax[4];
+            if (__ballot(shift >= 256u) == 0) {
+                // near/far planes were picked through the load address (see the quad kernel)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2 tnx = (half2of(nearX, h) - ox) * ix, tfx = (half2of(farX, h) - ox) * ix;
+                    const f2 tny = (half2of(nearY, h) - oy) * iy, tfy = (half2of(farY, h) - oy) * iy;
+                    const f2 tnz = (half2of(nearZ, h) - oz) * iz, tfz = (half2of(farZ, h) - oz) * iz;
+                    tmin[2 * h] = fmaxf(tnear, fmaxf(fmaxf(tnx.x, tny.x), tnz.x));
+                    tmin[2 * h + 1] = fmaxf(tnear, fmaxf(fmaxf(tnx.y, tny.y), tnz.y));
+                    tmax[2 * h] = fminf(tfar, fminf(fminf(tfx.x, tfy.x), tfz.x));
+                    tmax[2 * h + 1] = fminf(tfar, fminf(fminf(tfx.y, tfy.y), tfz.y));
+                }
+            } else {
+                // which of the two loaded arrays is min and which is max
+                const bool sxn = (offNX & 32u) != 0u, syn = (offNY & 32u) != 0u, szn = (offNZ & 32u) != 0u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float loX = sxn ? farX[i] : nearX[i], hiX = sxn ? nearX[i] : farX[i];
+                    const float loY = syn ? farY[i] : nearY[i], hiY = syn ? nearY[i] : farY[i];
+                    const float loZ = szn ? farZ[i] : nearZ[i], hiZ = szn ? nearZ[i] : farZ[i];
+                    const float tx1 = (loX - ox) * ix, tx2 = (hiX - ox) * ix; // :212-217
+                    const float ty1 = (loY - oy) * iy, ty2 = (hiY - oy) * iy;
+                    const float tz1 = (loZ - oz) * iz, tz2 = (hiZ - oz) * iz;
+                    const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
+                    const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
+                    tmin[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin))); // :224
+                    tmax[i] = min86(tfar, min86(txMax, min86(tyMax, tzMax)));  // :225
+                }
+            }
+            // slot j (far -> near) takes the child named by the octant permutation (:229-232,235); a child that fails
+            // tmin <= tmax (:233) travels as 0xFFFFFFFF
+            ldsStoreU4(slotBase + p * 32u, tmin[0] <= tmax[0] ? child4.x : 0xFFFFFFFFu, __float_as_uint(tmin[0]),
+                tmin[1] <= tmax[1] ? child4.y : 0xFFFFFFFFu, __float_as_uint(tmin[1]));
+            ldsStoreU4(slotBase + p * 32u + 16u, tmin[2] <= tmax[2] ? child4.z : 0xFFFFFFFFu, __float_as_uint(tmin[2]),
+                tmin[3] <= tmax[3] ? child4.w : 0xFFFFFFFFu, __float_as_uint(tmin[3]));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint2 s0 = ldsU2(slotBase + (__builtin_amdgcn_ubfe(perm4.x, shift, 3u) << 3));
+            const uint2 s1 = ldsU2(slotBase + (__builtin_amdgcn_ubfe(perm4.y, shift, 3u) << 3));
+            const uint2 s2 = ldsU2(slotBase + (__builtin_amdgcn_ubfe(perm4.z, shift, 3u) << 3));
+            const uint2 s3 = ldsU2(slotBase + (__builtin_amdgcn_ubfe(perm4.w, shift, 3u) << 3));
+            // compress (:234-237): slots are pushed in slot order; this lane's slots are 4p..4p+3
+            const uint32_t k0 = s0.x != 0xFFFFFFFFu ? 1u : 0u, k1 = s1.x != 0xFFFFFFFFu ? 1u : 0u;
+            const uint32_t k2 = s2.x != 0xFFFFFFFFu ? 1u : 0u, k3 = s3.x != 0xFFFFFFFFu ? 1u : 0u;
+            const uint32_t tot = (k0 + k1) + (k2 + k3);
+            const uint32_t other = uint32_t(pairSwap(int(tot)));
+            const uint32_t at0 = uint32_t(sp) + (other & belowMask);
+            const uint32_t at1 = at0 + k0, at2 = at1 + k1, at3 = at2 + k2;
+            const int spNew = sp + int(tot + other);
+            if (__ballot(uint32_t(spNew) > W) == 0) {
+                if (k0)
+                    ldsStoreU2(stackBase + at0 * 8u, s0);
+                if (k1)
+                    ldsStoreU2(stackBase + at1 * 8u, s1);
+                if (k2)
+                    ldsStoreU2(stackBase + at2 * 8u, s2);
+                if (k3)
+                    ldsStoreU2(stackBase + at3 * 8u, s3);
+            } else {
+                if (k0)
+                    stackStore(at0, s0);
+                if (k1)
+                    stackStore(at1, s1);
+                if (k2)
+                    stackStore(at2, s2);
+                if (k3)
+                    stackStore(at3, s3);
+            }
+            sp = spNew;
+            st = 1;
+            if (STATS)
+                statInner += (p == 0);
+        }
+
+        // ------------------------------------------------------------ retire rays whose stack ran dry
+        if (st == 1 && sp == 0) {
+            if (p == 0) {
+                const uint32_t off = rayId << 2;
+                if (ANY) {
+                    if (a.init_miss)
+                        at32(a.any_out, off) = 0u;
+                } else {
+                    at32(a.t_out, off) = tfar;
+                    if (hitObj != PGPU_MISS_ID) {
+                        at32(a.obj_out, off) = hitObj;
+                        at32(a.leaf_out, off) = tag;
+                        at32(a.u_out, off) = hitU;
+                        at32(a.v_out, off) = hitV;
+                    } else if (a.init_miss) {
+                        at32(a.obj_out, off) = PGPU_MISS_ID;
+                        at32(a.leaf_out, off) = 0u;
+                        at32(a.u_out, off) = 0.0f;
+                        at32(a.v_out, off) = 0.0f;
+                    }
+                }
+            }
+            st = 0;
+            shift = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        } // live rays
+    }
+
+    if (STATS && a.stats) {
+        atomicAdd(&a.stats[0], (unsigned long long)statInner);
+        atomicAdd(&a.stats[1], (unsigned long long)statLeaf);
+        atomicAdd(&a.stats[2], (unsigned long long)statTri);
+        if (lane == 0) {
+            atomicAdd(&a.stats[3], (unsigned long long)statIter);
+            atomicAdd(&a.stats[4], (unsigned long long)statLeafPass);
+            atomicAdd(&a.stats[5], (unsigned long long)statRefill);
+        }
+    }
+}
+
 } // namespace
 
-size_t bvh8TraceLdsBytes(uint32_t stackEntries)
+size_t bvh8TraceLdsBytes(uint32_t stackEntries, uint32_t lanesPerRay)
 {
+    if (lanesPerRay == 2u)
+        return kWavesPerBlock * kPairRaysPerWave * (kPairSlotBytes + stackStrideBytes(stackEntries));
     return kWavesPerBlock * kStagePerWave + kWavesPerBlock * kRaysPerWave * stackStrideBytes(stackEntries);
 }
 
 hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
 {
     const dim3 grid(blocks), block(256);
-    const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries);
-#define PANDORA_LAUNCH(ANYV, TRIV, STATV) \
-    hipLaunchKernelGGL((bvh8TraceKernel<ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args)
+    const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries, args.lanes_per_ray);
+#define PANDORA_LAUNCH(ANYV, TRIV, STATV)                                                                            \
+    do {                                                                                                             \
+        if (args.lanes_per_ray == 2u)                                                                                \
+            hipLaunchKernelGGL((bvh8TracePairKernel<ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args);       \
+        else                                                                                                         \
+            hipLaunchKernelGGL((bvh8TraceKernel<ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args);           \
+    } while (0)
     if (kind == PGPU_ANY_ID) {
         if (triMode == PGPU_TRI_WATERTIGHT_ID) {
             if (stats) PANDORA_LAUNCH(true, 1, true); else PANDORA_LAUNCH(true, 1, false);

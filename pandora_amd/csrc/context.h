@@ -38,7 +38,8 @@ struct pgpu_ctx {
     bool stats = false;
     int blocksPerCU = 0; // 0 = as many as LDS / registers allow
     uint32_t chunk = 64;
-    uint32_t refillMin = 3;
+    uint32_t refillMin = 0; // 0: automatic
+    uint32_t lanesPerRay = 4; // bottom-level kernel layout: 4 = 16 rays per wave, 2 = 32 rays per wave
     uint32_t leafMin = 0; // 0: automatic
     int stackWindow = 0;     // LDS stack entries per ray, 0 = automatic
     DeviceBuffer spill;      // global overflow of the per-ray stacks

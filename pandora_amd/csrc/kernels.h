@@ -51,6 +51,7 @@ struct Bvh8TraceArgs {
     unsigned long long* spill;
     uint32_t refill_min;    // refill idle ray groups once this many are idle
     uint32_t leaf_min;      // run the leaf (triangle) pass once this many ray groups of the wave wait for it
+    uint32_t lanes_per_ray; // 4: quad kernel (16 rays per wave), 2: pair kernel (32 rays per wave)
     unsigned long long* stats;
 };
 
@@ -121,7 +122,7 @@ hipError_t launchMergeResults(uint32_t k, const float* results, const uint32_t* 
     uint32_t* leaf, float* u, float* v, uint32_t* anyHit, uint32_t blocks, hipStream_t stream);
 hipError_t launchKeyCount(const uint32_t* keys, uint32_t n, uint32_t nKeys, uint32_t* counts, uint32_t blocks, hipStream_t stream);
 
-size_t bvh8TraceLdsBytes(uint32_t stackEntries);
+size_t bvh8TraceLdsBytes(uint32_t stackEntries, uint32_t lanesPerRay);
 inline uint32_t stackEntriesForDepth(uint32_t depth)
 {
     const uint32_t need = 7u * depth + 8u; // each inner visit pops 1 and pushes <= 8 (wive_bvh8_impl.h:97-102)
@@ -135,10 +136,10 @@ inline uint32_t stackWindow(uint32_t need, int requested)
     return need < cap ? need : cap;
 }
 // blocks of 256 threads per CU: requested, or (0) as many as LDS (160 KiB) and registers allow
-inline uint32_t blocksPerCU(int requested, uint32_t stackEntries)
+inline uint32_t blocksPerCU(int requested, uint32_t stackEntries, uint32_t lanesPerRay)
 {
-    const uint32_t byLds = uint32_t((160u * 1024u) / ((bvh8TraceLdsBytes(stackEntries) + 1023u) & ~size_t(1023))); // LDS is handed out in coarse granules
-    const uint32_t byRegs = 7u; // <= 72 VGPRs
+    const uint32_t byLds = uint32_t((160u * 1024u) / ((bvh8TraceLdsBytes(stackEntries, lanesPerRay) + 1023u) & ~size_t(1023))); // LDS is handed out in coarse granules
+    const uint32_t byRegs = lanesPerRay == 2u ? 4u : 7u; // <= 128 / <= 72 VGPRs
     const uint32_t cap = byLds < byRegs ? byLds : byRegs;
     if (requested <= 0)
         return cap < 1u ? 1u : cap;

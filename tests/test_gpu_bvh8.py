@@ -41,8 +41,10 @@ def _ray_sets(mesh, orc, res=96):
 # leaf_min: how many rays of a wave wait at a leaf before the triangle code runs (1 = every step)
 @pytest.mark.parametrize("refill_min,window,leaf_min", [(3, 0, 0), (1, 0, 1), (5, 0, 3), (2, 4, 16), (2, 1, 7), (16, 8, 0)])
 @pytest.mark.parametrize("tri_mode", [pa.capi.TRI_MT, pa.capi.TRI_WATERTIGHT])
-def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode, refill_min, window, leaf_min):
+@pytest.mark.parametrize("lanes", [4, 2], ids=["quad", "pair"])
+def test_closest_and_any_match_oracle(gpu_ctx, small, lanes, tri_mode, refill_min, window, leaf_min):
     mesh, hb, bvh, orc = small
+    gpu_ctx.set_ray_layout(lanes)
     gpu_ctx.set_kernel_variant(refill_min, window, leaf_min)
     for name, rays in _ray_sets(mesh, orc).items():
         got = gpu_ctx.trace_bvh8(bvh, rays, tri_mode=tri_mode)
@@ -51,4 +53,5 @@ def test_closest_and_any_match_oracle(gpu_ctx, small, tri_mode, refill_min, wind
         got_any = gpu_ctx.trace_bvh8(bvh, rays, kind=pa.capi.ANY, tri_mode=tri_mode)["hit"]
         want_any = orc.trace(rays, any_hit=True, tri_mode=tri_mode)["hit"]
         assert np.array_equal(got_any, want_any), f"{name}: any-hit differs"
-    gpu_ctx.set_kernel_variant(3, 0, 0)
+    gpu_ctx.set_kernel_variant(0, 0, 0)
+    gpu_ctx.set_ray_layout(4)
