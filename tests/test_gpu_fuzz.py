@@ -78,15 +78,18 @@ def test_hostile_rays_and_meshes(gpu_ctx, max_leaf):
     rays = _nasty_rays(rng, 40000)
     with np.errstate(all="ignore"):
         for tri in (pa.capi.TRI_MT, pa.capi.TRI_WATERTIGHT):
-            got = gpu_ctx.trace_bvh8(bvh, rays, tri_mode=tri)
             want = orc.trace(rays, tri_mode=tri, threads=8)
-            for k in ("t", "obj", "u", "v"):
-                g, w = _bits(got[k]), _bits(want[k])
-                bad = np.nonzero(g != w)[0]
-                assert bad.size == 0, f"tri{tri} {k}: {bad.size} rays differ, first {bad[:6]} rays {rays[:, bad[:3]].T}"
-            ga = gpu_ctx.trace_bvh8(bvh, rays, kind=pa.capi.ANY, tri_mode=tri)["hit"]
             wa = orc.trace(rays, any_hit=True, tri_mode=tri, threads=8)["hit"]
-            assert np.array_equal(ga, wa), f"tri{tri} any-hit: {(ga != wa).sum()} rays differ"
+            for lanes in (4, 2):  # both bottom-level kernel layouts
+                gpu_ctx.set_ray_layout(lanes)
+                got = gpu_ctx.trace_bvh8(bvh, rays, tri_mode=tri)
+                for k in ("t", "obj", "u", "v"):
+                    g, w = _bits(got[k]), _bits(want[k])
+                    bad = np.nonzero(g != w)[0]
+                    assert bad.size == 0, f"tri{tri} lanes{lanes} {k}: {bad.size} rays differ, first {bad[:6]} rays {rays[:, bad[:3]].T}"
+                ga = gpu_ctx.trace_bvh8(bvh, rays, kind=pa.capi.ANY, tri_mode=tri)["hit"]
+                assert np.array_equal(ga, wa), f"tri{tri} lanes{lanes} any-hit: {(ga != wa).sum()} rays differ"
+    gpu_ctx.set_ray_layout(4)
 
 
 @pytest.mark.parametrize("svdag", [0, 16])

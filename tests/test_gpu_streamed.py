@@ -33,7 +33,7 @@ def test_streamed_leaves_match_resident(svdag):
 
     ctx = pa.accel.Context(0)
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=True)
-    slot = max(((b.n_nodes * 256 + 255) // 256) * 256 + ((b.leaf_idx.size * 48 + 255) // 256) * 256 for b in tl.bvhs)
+    slot = max(((b.n_nodes * 256 + 255) // 256) * 256 + (((b.leaf_idx.size + 1) * 48 + 255) // 256) * 256 for b in tl.bvhs)  # (records end in one zero record of padding)
     for budget, label in ((0, "all fit"), (3 * slot + 17, "3 slots"), (slot, "1 slot")):
         ctx.set_leaf_cache(budget)
         for kind in (pa.capi.CLOSEST, pa.capi.ANY):

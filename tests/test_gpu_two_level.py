@@ -37,10 +37,11 @@ def _ray_sets(mesh):
     return {"primary": prim, "diffuse": diff, "shadow": shad, "random": rnd, "far": far}
 
 
-@pytest.mark.parametrize("window,leaf_min", [(0, 0), (2, 9)])
-def test_two_level_matches_oracle(two_level, window, leaf_min):
+@pytest.mark.parametrize("lanes,window,leaf_min", [(4, 0, 0), (4, 2, 9), (2, 0, 0), (2, 3, 5)])
+def test_two_level_matches_oracle(two_level, lanes, window, leaf_min):
     ctx, mesh, tl, orc = two_level
-    ctx.set_kernel_variant(3, window, leaf_min)
+    ctx.set_ray_layout(lanes)  # the bottom-level kernel's layout: quad (16 rays per wave) or pair (32)
+    ctx.set_kernel_variant(0, window, leaf_min)
     for name, rays in _ray_sets(mesh).items():
         got, cnt = ctx.trace(rays)
         want = orc.trace(rays, lanes=3)
