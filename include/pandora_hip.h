@@ -227,6 +227,18 @@ int pgpu_trace_leaf_records(pgpu_ctx*, int kind, int tri_mode, const float* reco
 int pgpu_route_merge(pgpu_ctx*, int kind, const float* results, const uint32_t* sent_slot, const uint32_t* sent_leaf, size_t k,
     const pgpu_hits* hits, uint32_t* any_hit, void* stream);
 
+/* Film. Sensor::addPixelContribution (graphics_core/sensor.cpp:36-49) over a batch of contributions:
+ * `film` holds three u64 per pixel in 40.24 fixed point (sensor.h:29-35), film[3 * pixel[i] + c] += fixed(rgb[i][c]).
+ * A contribution with a NaN or inf channel is dropped whole (sensor.cpp:41-42); so is one with |channel| >= 2^39 (outside
+ * the format, undefined in the reference) or pixel[i] >= n_pixels. Negative channels wrap (adding them subtracts).
+ * Integer adds commute: the film does not depend on the order of the contributions, and the films of several GPUs
+ * sum with an integer all-reduce. All pointers are device memory; the call only enqueues work on `stream` (NULL =
+ * the context's stream). pgpu_film_resolve is Sensor::Pixel -> vec3 (sensor.cpp:96-99): rgb_out[3 i + c] =
+ * float(film[3 i + c]) * 2^-24. */
+int pgpu_film_add(pgpu_ctx*, unsigned long long* film, size_t n_pixels, const uint32_t* pixel, const float* r, const float* g,
+    const float* b, size_t n, void* stream);
+int pgpu_film_resolve(pgpu_ctx*, const unsigned long long* film, size_t n_pixels, float* rgb_out, void* stream);
+
 /* Diagnostics: device time of the traversal kernels of the last trace call on this context, measured
  * with HIP events on the stream they ran on (ms); enables/disables visit counters. */
 float pgpu_last_kernel_ms(const pgpu_ctx*);

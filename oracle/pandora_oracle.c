@@ -871,3 +871,25 @@ void orc_brute_trace(const orc_mesh* m, size_t n_tris, int tri_mode, const float
     j.obj = prim;
     run_jobs(&j, n, n_threads, NULL);
 }
+
+/* ---------------------------------------------------------------- film (sensor.cpp:36-49, :86-99) */
+static uint64_t film_fixed(float c) { return (uint64_t)(int64_t)(c * 16777216.0f); } /* Pixel(color): scale by 2^24, truncate */
+
+void orc_film_add(uint64_t* film, size_t n_pixels, const uint32_t* pixel, const float* r, const float* g, const float* b, size_t n)
+{
+    const float lim = 549755813888.0f; /* 2^39: beyond it the 40.24 format cannot hold the value (undefined in the reference) */
+    for (size_t i = 0; i < n; ++i) {
+        const float c[3] = { r[i], g[i], b[i] };
+        /* :41-42: NaN / inf in any channel drops the contribution (every comparison with NaN is false) */
+        if (!(pixel[i] < n_pixels && fabsf(c[0]) < lim && fabsf(c[1]) < lim && fabsf(c[2]) < lim))
+            continue;
+        for (int k = 0; k < 3; ++k)
+            film[(size_t)pixel[i] * 3 + (size_t)k] += film_fixed(c[k]); /* :44-48: the CAS loop is an atomic add */
+    }
+}
+
+void orc_film_resolve(const uint64_t* film, size_t n_pixels, float* rgb_out)
+{
+    for (size_t i = 0; i < n_pixels * 3; ++i)
+        rgb_out[i] = (float)film[i] * 5.9604644775390625e-08f;
+}

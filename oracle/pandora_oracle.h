@@ -155,6 +155,12 @@ void orc_scene_trace(const orc_scene* s, int any_hit, int tri_mode, int svdag_la
 void orc_brute_trace(const orc_mesh* m, size_t n_tris, int tri_mode, const float* rays, size_t n,
     float* t, uint32_t* prim, int n_threads);
 
+/* Film: Sensor::addPixelContribution over a batch (graphics_core/sensor.cpp:36-49, sensor.h:29-35; the fixed-point type
+ * is cnl::fixed_point<uint64_t, -24>, a dependency that is not in the container: restated from its definition, parity
+ * unpinned). film: 3 u64 per pixel. */
+void orc_film_add(uint64_t* film, size_t n_pixels, const uint32_t* pixel, const float* r, const float* g, const float* b, size_t n);
+void orc_film_resolve(const uint64_t* film, size_t n_pixels, float* rgb_out); /* sensor.cpp:96-99 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,6 +356,16 @@ class Context:
         _check(self._L.pgpu_route_merge(self._h, kind, capi.ptr(results), capi.ptr(sent_slot), capi.ptr(sent_leaf), k, C.byref(h) if h is not None else None,
                                         capi.ptr(any_hit), stream), self._h)
 
+    def film_add(self, film, pixel, r, g, b, stream: int = 0):
+        """Sensor::addPixelContribution over a batch (sensor.cpp:36-49). film: int64 device tensor [n_pixels, 3] (40.24
+        fixed point); pixel: int32 device tensor [n]; r, g, b: float32 device tensors [n]. Enqueues on `stream`."""
+        n_pixels = int(film.numel() // 3)
+        _check(self._L.pgpu_film_add(self._h, capi.ptr(film), n_pixels, capi.ptr(pixel), capi.ptr(r), capi.ptr(g), capi.ptr(b), int(pixel.numel()), stream), self._h)
+
+    def film_resolve(self, film, out, stream: int = 0):
+        """Sensor::Pixel -> vec3 (sensor.cpp:96-99): out (float32 device tensor [n_pixels, 3]) = film * 2^-24."""
+        _check(self._L.pgpu_film_resolve(self._h, capi.ptr(film), int(film.numel() // 3), capi.ptr(out), stream), self._h)
+
     def sync(self, stream: int = 0):
         _check(self._L.pgpu_sync(self._h, stream), self._h)
 

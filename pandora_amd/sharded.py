@@ -56,6 +56,17 @@ def reduce_job(elapsed_s: float, n_units: int, device=None):
     return float(t.item()), int(n.item())
 
 
+def film_allreduce(film: torch.Tensor) -> torch.Tensor:
+    """Sums the per-rank films (int64, 40.24 fixed point, see Context.film_add) in place. Integer addition is associative,
+    so the result is the film one process would have accumulated from all contributions, bit for bit, whatever the
+    number of ranks (the property the reference's fixed-point sensor exists for, sensor.h:29-30)."""
+    if film.dtype != torch.int64:
+        raise ValueError("film_allreduce: the film is an int64 tensor")
+    if _world()[1] > 1:
+        dist.all_reduce(film, op=dist.ReduceOp.SUM)
+    return film
+
+
 def _world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 

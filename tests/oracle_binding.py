@@ -189,6 +189,26 @@ def brute(mesh, rays: np.ndarray, tri_mode=0, threads=4):
     return t, prim
 
 
+def film_add(film: np.ndarray, pixel, r, g, b) -> None:
+    """orc_film_add on a uint64 array [n_pixels, 3] (in place)."""
+    assert film.dtype == np.uint64 and film.flags.c_contiguous
+    pixel = np.ascontiguousarray(pixel, np.uint32)
+    r, g, b = (np.ascontiguousarray(x, np.float32) for x in (r, g, b))
+    f = oracle().orc_film_add
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    f.restype = None
+    f(film.ctypes.data, film.size // 3, pixel.ctypes.data, r.ctypes.data, g.ctypes.data, b.ctypes.data, pixel.size)
+
+
+def film_resolve(film: np.ndarray) -> np.ndarray:
+    out = np.zeros(film.shape, np.float32)
+    f = oracle().orc_film_resolve
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    f.restype = None
+    f(np.ascontiguousarray(film).ctypes.data, film.size // 3, out.ctypes.data)
+    return out
+
+
 def scene_from_two_level(tl, mesh) -> OracleScene:
     """OracleScene for a pandora_amd.accel.TwoLevelScene (leaves in final slot order)."""
     leaf_bvhs = [OracleBvh8.from_host(tl.bvhs[int(src)], mesh) for src in tl.top.leaf_order]
