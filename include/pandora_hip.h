@@ -151,6 +151,15 @@ int pgpu_bvh8_serialize(const void* nodes256, size_t n_nodes, const uint32_t* le
 int pgpu_bvh8_deserialize(const void* bytes, size_t size, const void** nodes256, size_t* n_nodes, const uint32_t** leaf_indices,
     size_t* n_leaf_indices, uint32_t* root_handle, uint64_t* num_leaf_objects);
 void pgpu_bytes_free(void* bytes);
+/* The triangle mesh chunk of the reference (pandora/flatbuffers/triangle_mesh.fbs: indices [Vec3u], positions [Vec3], normals
+ * [Vec3], texCoords [Vec2], bounds), as TriangleShape::serialize writes it (shapes/triangle_shape.cpp:520-553) and
+ * TriangleShape::loadSerialized reads it (:557-611). normals / texcoords may be NULL (left out, as the reference does for empty
+ * ones); bounds are those of the positions. The reader returns pointers into `bytes` (every offset bounds-checked; absent vectors
+ * read as empty) and does not validate the index values -- pgpu_upload_mesh does. Free the writer's buffer with pgpu_bytes_free. */
+int pgpu_mesh_serialize(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles, const float* normals,
+    const float* texcoords, void** out_bytes, size_t* out_size);
+int pgpu_mesh_deserialize(const void* bytes, size_t size, const float** positions, size_t* n_vertices, const uint32_t** indices,
+    size_t* n_triangles, const float** normals, size_t* n_normals, const float** texcoords, size_t* n_texcoords, float* bounds6);
 
 /* ------------------------------------------------------------------ tracing
  * SoA ray batch: Ray{origin, direction, tnear, tfar} of graphics_core/ray.h:14-40. */

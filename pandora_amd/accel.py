@@ -85,6 +85,44 @@ def bvh8_to_bytes(bvh: HostBvh8) -> bytes:
         L.pgpu_bytes_free(out)
 
 
+def mesh_to_bytes(pos: np.ndarray, idx: np.ndarray, normals: np.ndarray | None = None, texcoords: np.ndarray | None = None) -> bytes:
+    """The reference's triangle mesh chunk (triangle_mesh.fbs) as TriangleShape::serialize writes it (triangle_shape.cpp:520-553)."""
+    L = capi.lib()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    tex = None if texcoords is None else np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
+    if (nrm is not None and nrm.shape[0] != pos.shape[0]) or (tex is not None and tex.shape[0] != pos.shape[0]):
+        raise PandoraError(capi.ERR_INVALID, "mesh_to_bytes: one normal / texture coordinate per vertex")
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(L.pgpu_mesh_serialize(pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], capi.ptr(nrm), capi.ptr(tex), C.byref(out), C.byref(n)),
+           what="pgpu_mesh_serialize failed")
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        L.pgpu_bytes_free(out)
+
+
+def mesh_from_bytes(data: bytes) -> dict:
+    """Reads a triangle mesh chunk: {"pos", "idx", "normals", "texcoords", "bounds"} (copies; empty arrays for absent vectors)."""
+    L = capi.lib()
+    buf = np.frombuffer(data, np.uint8)
+    ptrs = [C.c_void_p() for _ in range(4)]
+    cnts = [C.c_size_t() for _ in range(4)]
+    bounds = np.zeros(6, np.float32)
+    _check(L.pgpu_mesh_deserialize(buf.ctypes.data, buf.size, C.byref(ptrs[0]), C.byref(cnts[0]), C.byref(ptrs[1]), C.byref(cnts[1]), C.byref(ptrs[2]),
+                                   C.byref(cnts[2]), C.byref(ptrs[3]), C.byref(cnts[3]), bounds.ctypes.data), what="pgpu_mesh_deserialize: not a TriangleMesh flatbuffer")
+
+    def take(i, dtype, width):
+        n = int(cnts[i].value)
+        if n == 0:
+            return np.zeros((0, width), dtype)
+        return np.frombuffer(data, dtype, count=n * width, offset=ptrs[i].value - buf.ctypes.data).reshape(n, width).copy()
+
+    return {"pos": take(0, np.float32, 3), "idx": take(1, np.uint32, 3), "normals": take(2, np.float32, 3), "texcoords": take(3, np.float32, 2),
+            "bounds": bounds.reshape(2, 3)}
+
+
 def bvh8_from_bytes(data: bytes, prim_ids: np.ndarray) -> HostBvh8:
     L = capi.lib()
     buf = np.frombuffer(data, np.uint8)

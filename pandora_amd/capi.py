@@ -102,6 +102,8 @@ SYMBOLS = {
     "pgpu_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pgpu_set_kernel_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pgpu_set_ray_layout": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgpu_mesh_serialize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgpu_mesh_deserialize": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),
     "pgpu_film_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgpu_film_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

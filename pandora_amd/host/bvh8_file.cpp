@@ -1,4 +1,5 @@
-// On-disk form of a bottom-level BVH8: the flatbuffer the reference writes for a cached BVH
+// On-disk forms on either side of the traversal path: the cached bottom-level BVH8 and the triangle mesh chunk (at the end of this file).
+// BVH8: the flatbuffer the reference writes for a cached BVH
 //   table WiVeBVH8 { innerNodeAllocator, leafIndexAllocator : ContiguousAllocator; compressedRootHandle : uint32; numLeafObjects : ulong }
 //   table ContiguousAllocator { maxSize, blockSize, currentSize : uint32; data : [byte] }
 // (pandora/flatbuffers/wive_bvh8.fbs, contiguous_allocator.fbs; written by WiVeBVH8::serialize, wive_bvh8_impl.h:37-49,
@@ -13,6 +14,7 @@
 // can produce one).
 #include "pandora_hip.h"
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -59,6 +61,20 @@ public:
         preAlign(n, 4); // so that the length prefix ends up 4-aligned
         pushBytes(p, n);
         return push<uint32_t>(uint32_t(n));
+    }
+    // CreateVectorOfStructs for structs of 4-byte scalars: `count` elements of `elemBytes` each, length prefix = count
+    size_t createStructVector(const void* p, size_t count, size_t elemBytes)
+    {
+        preAlign(count * elemBytes, 4);
+        pushBytes(p, count * elemBytes);
+        return push<uint32_t>(uint32_t(count));
+    }
+    // AddStruct: the struct is stored inline in the table
+    void addStruct(uint16_t voffset, const void* p, size_t bytes, size_t alignment)
+    {
+        align(alignment);
+        pushBytes(p, bytes);
+        m_fields.push_back({ voffset, size() });
     }
     void startTable()
     {
@@ -235,7 +251,7 @@ bool readAllocator(const View& v, size_t pos, AllocatorView* a)
         return false;
     if (vec == 0)
         return a->currentSize == 0;
-    if (!v.read(vec, &a->bytes) || !v.ok(vec + 4, a->bytes))
+    if ((vec & 3u) != 0 || !v.read(vec, &a->bytes) || !v.ok(vec + 4, a->bytes)) // (the format aligns every vector to 4 bytes)
         return false;
     a->data = v.p + vec + 4;
     return true;
@@ -278,8 +294,9 @@ void pgpu_bytes_free(void* bytes) { std::free(bytes); }
 int pgpu_bvh8_deserialize(const void* bytes, size_t size, const void** nodes256, size_t* n_nodes, const uint32_t** leaf_indices,
     size_t* n_leaf_indices, uint32_t* root_handle, uint64_t* num_leaf_objects)
 {
-    if (!bytes || !nodes256 || !n_nodes || !leaf_indices || !n_leaf_indices || !root_handle || !num_leaf_objects)
-        return PGPU_ERR_INVALID;
+    if (!bytes || !nodes256 || !n_nodes || !leaf_indices || !n_leaf_indices || !root_handle || !num_leaf_objects
+        || (reinterpret_cast<uintptr_t>(bytes) & 3u) != 0)
+        return PGPU_ERR_INVALID; // (the buffer itself must be 4-byte aligned, as any allocation or file mapping is)
     const View v { static_cast<const unsigned char*>(bytes), size };
     uint32_t rootRel;
     Table root;
@@ -297,6 +314,101 @@ int pgpu_bvh8_deserialize(const void* bytes, size_t size, const void** nodes256,
     *n_nodes = inner.currentSize;
     *leaf_indices = reinterpret_cast<const uint32_t*>(leaf.data);
     *n_leaf_indices = leaf.currentSize;
+    return PGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Triangle mesh chunk: table TriangleMesh { indices : [Vec3u]; positions : [Vec3]; normals : [Vec3]; texCoords : [Vec2]; bounds : Bounds }
+// (pandora/flatbuffers/triangle_mesh.fbs, data_types.fbs), written by TriangleShape::serialize (shapes/triangle_shape.cpp:520-553: vectors
+// created in the order indices, positions, normals, texCoords; absent normals / texCoords are left out; bounds inline) and read by
+// TriangleShape::loadSerialized (:557-611) -- the geometry the traversal path's leaves point at.
+int pgpu_mesh_serialize(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles, const float* normals,
+    const float* texcoords, void** out_bytes, size_t* out_size)
+{
+    if (!out_bytes || !out_size || (n_vertices && !positions) || (n_triangles && !indices) || n_vertices > 0x0FFFFFFFu || n_triangles > 0x0FFFFFFFu)
+        return PGPU_ERR_INVALID;
+    *out_bytes = nullptr;
+    *out_size = 0;
+    float bounds[6] = { 3.402823466e38f, 3.402823466e38f, 3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f }; // Bounds::reset
+    for (size_t i = 0; i < n_vertices; ++i)
+        for (int a = 0; a < 3; ++a) {
+            bounds[a] = std::min(bounds[a], positions[3 * i + size_t(a)]);
+            bounds[3 + a] = std::max(bounds[3 + a], positions[3 * i + size_t(a)]);
+        }
+    BackwardBuilder b(n_triangles * 12 + n_vertices * (12 + (normals ? 12 : 0) + (texcoords ? 8 : 0)) + 256);
+    const size_t vIdx = b.createStructVector(indices, n_triangles, 12);
+    const size_t vPos = b.createStructVector(positions, n_vertices, 12);
+    const size_t vNrm = normals ? b.createStructVector(normals, n_vertices, 12) : 0;
+    const size_t vTex = texcoords ? b.createStructVector(texcoords, n_vertices, 8) : 0;
+    b.startTable(); // CreateTriangleMesh: every field is 4 bytes wide to the sorter, so reverse declaration order
+    b.addStruct(fieldVoffset(4), bounds, sizeof(bounds), 4);
+    if (vTex)
+        b.addOffset(fieldVoffset(3), vTex);
+    if (vNrm)
+        b.addOffset(fieldVoffset(2), vNrm);
+    b.addOffset(fieldVoffset(1), vPos);
+    b.addOffset(fieldVoffset(0), vIdx);
+    b.finish(b.endTable());
+    void* out = std::malloc(std::max<size_t>(b.size(), 1));
+    if (!out)
+        return PGPU_ERR_INVALID;
+    std::memcpy(out, b.data(), b.size());
+    *out_bytes = out;
+    *out_size = b.size();
+    return PGPU_OK;
+}
+
+int pgpu_mesh_deserialize(const void* bytes, size_t size, const float** positions, size_t* n_vertices, const uint32_t** indices,
+    size_t* n_triangles, const float** normals, size_t* n_normals, const float** texcoords, size_t* n_texcoords, float* bounds6)
+{
+    if (!bytes || !positions || !n_vertices || !indices || !n_triangles || (reinterpret_cast<uintptr_t>(bytes) & 3u) != 0)
+        return PGPU_ERR_INVALID; // (the buffer itself must be 4-byte aligned, as any allocation or file mapping is)
+    const View v { static_cast<const unsigned char*>(bytes), size };
+    uint32_t rootRel;
+    Table root;
+    if (!v.read(0, &rootRel) || rootRel < 4 || !openTable(v, rootRel, &root))
+        return PGPU_ERR_INVALID;
+    auto structVector = [&](unsigned field, size_t elemBytes, const unsigned char** data, size_t* count) {
+        size_t vec;
+        uint32_t n = 0;
+        *data = nullptr;
+        *count = 0;
+        if (!offsetField(v, root, field, &vec))
+            return false;
+        if (vec == 0)
+            return true; // absent: an empty vector
+        if ((vec & 3u) != 0 || !v.read(vec, &n) || uint64_t(n) * elemBytes > size || !v.ok(vec + 4, size_t(n) * elemBytes))
+            return false; // (the format aligns every vector to 4 bytes: the typed pointers handed back rely on it)
+        *data = v.p + vec + 4;
+        *count = n;
+        return true;
+    };
+    const unsigned char *pIdx, *pPos, *pNrm, *pTex;
+    size_t nIdx, nPos, nNrm, nTex;
+    if (!structVector(0, 12, &pIdx, &nIdx) || !structVector(1, 12, &pPos, &nPos) || !structVector(2, 12, &pNrm, &nNrm) || !structVector(3, 8, &pTex, &nTex))
+        return PGPU_ERR_INVALID;
+    size_t at;
+    if (!fieldAt(v, root, 4, 24, &at) || !v.ok(at, at ? 24 : 0))
+        return PGPU_ERR_INVALID;
+    if (bounds6) {
+        if (at)
+            std::memcpy(bounds6, v.p + at, 24);
+        else
+            std::memset(bounds6, 0, 24);
+    }
+    // (values are read in place: 4-byte alignment relative to the start of the buffer is what the format gives)
+    *indices = reinterpret_cast<const uint32_t*>(pIdx);
+    *n_triangles = nIdx;
+    *positions = reinterpret_cast<const float*>(pPos);
+    *n_vertices = nPos;
+    if (normals)
+        *normals = reinterpret_cast<const float*>(pNrm);
+    if (n_normals)
+        *n_normals = nNrm;
+    if (texcoords)
+        *texcoords = reinterpret_cast<const float*>(pTex);
+    if (n_texcoords)
+        *n_texcoords = nTex;
     return PGPU_OK;
 }
 }
