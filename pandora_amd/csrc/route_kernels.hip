@@ -192,9 +192,19 @@ __global__ __launch_bounds__(256) void mergeResultsKernel(uint32_t k, const floa
     }
 }
 
-// counts[key] += 1 for every key < nKeys (global atomics, wave-aggregated): the leaf histogram of received work
+// counts[key] += 1 for every key < nKeys: the leaf histogram of received work. Coherent batches put most of their rays on a
+// handful of keys, and global atomics on one address serialise across the chip (the same effect that made the first top-level
+// kernel 60x slower): a block therefore counts in LDS (wave-aggregated) and flushes its non-zero counters once, one global
+// atomic each. IN_LDS = false (more keys than fit): wave-aggregated global atomics.
+template <bool IN_LDS>
 __global__ __launch_bounds__(256) void keyCountKernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t nKeys, uint32_t* __restrict__ counts)
 {
+    extern __shared__ uint32_t ldsCounts[];
+    if (IN_LDS) {
+        for (uint32_t k = threadIdx.x; k < nKeys; k += 256u)
+            ldsCounts[k] = 0u;
+        __syncthreads();
+    }
     for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t key = i < n ? keys[i] : PGPU_MISS_ID;
@@ -202,7 +212,15 @@ __global__ __launch_bounds__(256) void keyCountKernel(const uint32_t* __restrict
         if (__ballot(live) != 0) {
             const KeyGroup kg = groupByKey(key, live);
             if (live && kg.leader == (threadIdx.x & 63u))
-                atomicAdd(&counts[key], kg.size);
+                atomicAdd(IN_LDS ? &ldsCounts[key] : &counts[key], kg.size);
+        }
+    }
+    if (IN_LDS) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nKeys; k += 256u) {
+            const uint32_t c = ldsCounts[k];
+            if (c)
+                atomicAdd(&counts[k], c);
         }
     }
 }
@@ -253,7 +271,10 @@ hipError_t launchMergeResults(uint32_t k, const float* results, const uint32_t* 
 
 hipError_t launchKeyCount(const uint32_t* keys, uint32_t n, uint32_t nKeys, uint32_t* counts, uint32_t blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(keyCountKernel, dim3(blocks), dim3(256), 0, stream, keys, n, nKeys, counts);
+    if (nKeys <= 8192u)
+        hipLaunchKernelGGL(keyCountKernel<true>, dim3(blocks), dim3(256), size_t(nKeys) * 4u, stream, keys, n, nKeys, counts);
+    else
+        hipLaunchKernelGGL(keyCountKernel<false>, dim3(blocks), dim3(256), 0, stream, keys, n, nKeys, counts);
     return hipGetLastError();
 }
 
