@@ -130,6 +130,10 @@ def main() -> None:
                    "sample": f"first {sample} rays of the same R-diffuse batch, oracle/pandora_oracle.c (scalar restatement of WiVeBVH8::intersect), {threads} pthreads",
                    "gpu_matches_bit_exact": bool(same),
                    "visits_per_ray": {k: want["counters"][k] / sample for k in ("inner_visits", "leaf_pops", "tri_tests")}}
+            # SURVEY.md 8d, secondary figure: bytes a ray pulls through the caches (256 B per inner visit, 4 B per leaf index,
+            # 48 B per triangle record), from the oracle's visit counters -- what L2 / Infinity Cache must serve
+            vpr = cpu["visits_per_ray"]
+            cpu["traversal_model_bytes_per_ray"] = 256.0 * vpr["inner_visits"] + 4.0 * vpr["tri_tests"] + 48.0 * vpr["tri_tests"]
         # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command
         # (tools/pmc_passes.sh), which cannot run inside the timed process; the committed summary is quoted.
         traffic, traffic_src = None, None
@@ -151,6 +155,8 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "scene_bytes": scene_bytes},
             "cpu_baseline": cpu,
         }
+        if cpu is not None:
+            line["roofline"]["traversal_model_GBps"] = cpu["traversal_model_bytes_per_ray"] * n / (k_ms * 1e-3) / 1e9
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
