@@ -55,3 +55,30 @@ def test_closest_and_any_match_oracle(gpu_ctx, small, lanes, tri_mode, refill_mi
         assert np.array_equal(got_any, want_any), f"{name}: any-hit differs"
     gpu_ctx.set_kernel_variant(0, 0, 0)
     gpu_ctx.set_ray_layout(4)
+
+
+@pytest.mark.parametrize("lanes", [4, 2], ids=["quad", "pair"])
+def test_traversal_work_equals_the_reference_algorithm(gpu_ctx, small, lanes):
+    """The kernels cull lazily at pop time where the reference compacts its stack after every hit: the two are
+    claimed equivalent, so the GPU must visit exactly as many inner nodes, pop as many leaves and test as many triangles as
+    the CPU restatement of the reference's loop does -- whatever the scheduling knobs."""
+    mesh, hb, bvh, orc = small
+    gpu_ctx.set_ray_layout(lanes)
+    gpu_ctx.set_stats(True)
+    try:
+        for (refill_min, window, leaf_min) in ((0, 0, 0), (1, 2, 1), (9, 5, 11)):
+            gpu_ctx.set_kernel_variant(refill_min, window, leaf_min)
+            for name, rays in _ray_sets(mesh, orc, res=64).items():
+                for any_hit in (False, True):
+                    gpu_ctx.trace_bvh8(bvh, rays, kind=pa.capi.ANY if any_hit else pa.capi.CLOSEST)
+                    got = gpu_ctx.counters()
+                    want = orc.trace(rays, any_hit=any_hit)["counters"]
+                    # (any-hit: the reference leaves a leaf at its first hit, wive_bvh8_impl.h:282-290; the kernels test the leaf's
+                    # <= 4 triangles side by side, so they count the ones after it too)
+                    for k in ("inner_visits", "leaf_pops") + (() if any_hit else ("tri_tests",)):
+                        assert got[k] == want[k], f"{name} any={any_hit} variant {(refill_min, window, leaf_min)}: {k} {got[k]} != {want[k]}"
+                    assert got["tri_tests"] >= want["tri_tests"]
+    finally:
+        gpu_ctx.set_stats(False)
+        gpu_ctx.set_kernel_variant(0, 0, 0)
+        gpu_ctx.set_ray_layout(4)
