@@ -10,6 +10,7 @@ All computation happens in libpandora_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -472,7 +473,14 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     counts = np.bincount(group_of, minlength=ng)
     starts = np.concatenate([[0], np.cumsum(counts)])
     groups = [np.ascontiguousarray(order[starts[g]:starts[g + 1]]) for g in range(ng)]
-    bvhs = [build_bvh8(pos, idx, g, max_leaf) for g in groups]
+    # the per-group builds are independent C calls (ctypes releases the GIL): run them on a few threads
+    workers = max(1, min(16, os.cpu_count() or 1, len(groups)))
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            bvhs = list(pool.map(lambda g: build_bvh8(pos, idx, g, max_leaf), groups))
+    else:
+        bvhs = [build_bvh8(pos, idx, g, max_leaf) for g in groups]
     bounds = np.empty((ng, 6), np.float32)
     for g, prims in enumerate(groups):
         v = pos[idx[prims].ravel()]
