@@ -256,7 +256,7 @@ float pgpu_last_kernel_ms(const pgpu_ctx*);
 int pgpu_sync(pgpu_ctx*, void* stream);
 int pgpu_set_stats(pgpu_ctx*, int enabled);
 int pgpu_get_counters(pgpu_ctx*, pgpu_counters* out);
-int pgpu_set_tuning(pgpu_ctx*, int blocks_per_cu, int chunk); /* blocks_per_cu 0 = automatic */
+int pgpu_set_tuning(pgpu_ctx*, int blocks_per_cu, int chunk); /* 0 = automatic (both) */
 /* Bottom-level kernel scheduling knobs: how many of a wave's rays must have finished before new rays
  * are fetched (0 = automatic), how many entries of each ray's traversal stack stay in LDS (0 = automatic; deeper entries
  * spill to HBM), and how many rays of a wave must wait at a leaf before the wave runs its triangle code

@@ -147,6 +147,8 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a,
     a.stack_entries = window;
     a.refill_min = c->refillMin ? c->refillMin : (lanes == 2u ? 6u : 3u);
     a.n_bvhs = uint32_t(c->bvhs.size());
+    if (a.chunk == 0)
+        a.chunk = n_work >= (size_t(1) << 18) ? 128u : 64u; // automatic: large batches amortise the cursor atomics over more rays (measured)
     a.range_size = uint32_t((((n_work + 7) / 8 + a.chunk - 1) / a.chunk) * a.chunk);
     a.leaf_min = c->leafMin ? c->leafMin : (lanes == 2u ? 8u : 4u);
     a.spill_entries = need > window ? need - window : 0u;
@@ -262,7 +264,7 @@ int pgpu_set_stats(pgpu_ctx* c, int enabled)
 
 int pgpu_set_tuning(pgpu_ctx* c, int blocks_per_cu, int chunk)
 {
-    if (!c || blocks_per_cu < 0 || blocks_per_cu > 8 || chunk < 8 || chunk > 65536)
+    if (!c || blocks_per_cu < 0 || blocks_per_cu > 8 || (chunk != 0 && chunk < 8) || chunk > 65536)
         return PGPU_ERR_INVALID;
     c->blocksPerCU = blocks_per_cu;
     c->chunk = uint32_t(chunk);

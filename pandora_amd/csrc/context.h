@@ -37,7 +37,7 @@ struct pgpu_ctx {
     float lastKernelMs = 0.0f;
     bool stats = false;
     int blocksPerCU = 0; // 0 = as many as LDS / registers allow
-    uint32_t chunk = 64;
+    uint32_t chunk = 0; // work items a wave draws at a time, 0 = automatic
     uint32_t refillMin = 0; // 0: automatic
     uint32_t lanesPerRay = 4; // bottom-level kernel layout: 4 = 16 rays per wave, 2 = 32 rays per wave
     uint32_t leafMin = 0; // 0: automatic

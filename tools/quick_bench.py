@@ -52,7 +52,7 @@ for rmin, bpc, chunk, win, lmin in variants:
         lpr, rmin, bpc, chunk, win, lmin, min(ms), sorted(ms)[2], n / min(ms) / 1e3, cn["wave_steps"] / 1e6, cn["leaf_passes"] / 1e6, cn["refill_passes"] / 1e6,
         (cn["inner_visits"] + cn["leaf_pops"]) / max(1, cn["wave_steps"] * g)), flush=True)
 ctx.set_kernel_variant(0, 0, 0)
-ctx.set_tuning(0, 64)
+ctx.set_tuning(0, 0)
 ms = []
 for it in range(5):
     ctx.trace_bvh8(bvh, ddiff, kind=pa.capi.ANY); ctx.sync(); ms.append(ctx.last_kernel_ms())
