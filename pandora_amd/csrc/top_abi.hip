@@ -422,8 +422,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     uint64_t rounds = 0, leafVisits = 0;
     uint32_t nActive = uint32_t(n);
     const uint32_t* active = nullptr; // round 0: every ray, identity order
-    // blocks of 256 per CU the top-level kernel can keep resident: LDS (160 KiB) and registers (<= 80 VGPRs: 6 waves per SIMD)
-    const uint32_t topPerCU = uint32_t(std::max<size_t>(1, std::min<size_t>(6, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
+    // blocks of 256 per CU the top-level kernel can keep resident: LDS (160 KiB) and registers (64 VGPRs: 8 waves per SIMD)
+    const uint32_t topPerCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
     const uint32_t topMaxBlocks = uint32_t(c->numCUs) * topPerCU;
     while (nActive > 0) {
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
@@ -624,7 +624,7 @@ int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_
     ta.counters = c->topCounters;
     ta.step_cap = uint32_t(std::min<uint64_t>(0xFFFFFFF0ull, 8ull * (uint64_t(c->top.n_nodes) + c->top.n_leaves) + 64ull));
     ta.may_park = may_park ? 1u : 0u;
-    const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(6, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
+    const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
     const uint32_t blocks = std::max(1u, std::min(uint32_t(c->numCUs) * perCU, uint32_t((n_active + 255) / 256)));
     HIP_TRY(c, launchTopTraverse(ta, kind, blocks, stream));
     c->topCountersDirty = true;

@@ -186,7 +186,7 @@ __device__ __forceinline__ KeyGroup groupByKey(uint32_t key, bool active)
 }
 
 template <bool ANY, bool NODES_IN_LDS>
-__global__ __launch_bounds__(kTopBlock) void topTraverseKernel(TopTraceArgs a)
+__global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void topTraverseKernel(TopTraceArgs a)
 {
     // dynamic LDS: [dag_levels x 256 saved parents of the SVDAG cast][the top-level nodes, when they fit]
     // [2 SVDAG counters + one counter per batching point, when they fit]
