@@ -111,3 +111,24 @@ def test_truncated_and_corrupted_buffers_are_rejected_or_read_safely():
             assert back["pos"].size <= len(data) and back["idx"].size <= len(data)
         except pa.capi.PandoraError:
             pass
+
+
+def test_bad_arguments_are_rejected():
+    import ctypes as C
+    L = pa.capi.lib()
+    out, n = C.c_void_p(), C.c_size_t()
+    pos = np.zeros((3, 3), np.float32)
+    idx = np.zeros((1, 3), np.uint32)
+    assert L.pgpu_mesh_serialize(None, 3, idx.ctypes.data, 1, None, None, C.byref(out), C.byref(n)) == pa.capi.ERR_INVALID
+    assert L.pgpu_mesh_serialize(pos.ctypes.data, 3, None, 1, None, None, C.byref(out), C.byref(n)) == pa.capi.ERR_INVALID
+    assert L.pgpu_mesh_serialize(pos.ctypes.data, 3, idx.ctypes.data, 1, None, None, None, C.byref(n)) == pa.capi.ERR_INVALID
+    assert L.pgpu_mesh_deserialize(None, 0, *([None] * 9)) == pa.capi.ERR_INVALID
+    data = pa.accel.mesh_to_bytes(pos, idx)
+    buf = np.frombuffer(data + b"\0" * 8, np.uint8)
+    ptrs = [C.c_void_p() for _ in range(2)]
+    cnts = [C.c_size_t() for _ in range(2)]
+    # a buffer that does not start on a 4-byte boundary cannot hand out float / u32 pointers
+    assert L.pgpu_mesh_deserialize(buf.ctypes.data + 1, len(data), C.byref(ptrs[0]), C.byref(cnts[0]), C.byref(ptrs[1]), C.byref(cnts[1]), None, None, None, None, None) == pa.capi.ERR_INVALID
+    # the optional outputs may be left out
+    assert L.pgpu_mesh_deserialize(buf.ctypes.data, len(data), C.byref(ptrs[0]), C.byref(cnts[0]), C.byref(ptrs[1]), C.byref(cnts[1]), None, None, None, None, None) == pa.capi.OK
+    assert cnts[0].value == 3 and cnts[1].value == 1
