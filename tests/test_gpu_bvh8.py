@@ -33,7 +33,14 @@ def _ray_sets(mesh, orc, res=96):
     diff = pa.scenes.diffuse_bounce_rays(mesh, prim, w["t"], w["obj"])
     shad = pa.scenes.shadow_rays(mesh, prim, w["t"], w["obj"], (-0.3, 1.99, -0.3), (0.3, 1.99, 0.3))
     rnd = pa.scenes.random_rays((-3, -1, -3), (3, 3, 3), 5000, seed=3)
-    return {"primary": prim, "diffuse": diff, "shadow": shad, "random": rnd}
+    # Rays that pass exactly through (0, 0, 0): the unused child slots of a node are zero boxes with handle 0
+    # (wive_bvh8_build8_impl.h:142-144), such a ray "hits" them (tmin == tmax) and the reference then treats handle 0 as a
+    # one-triangle leaf at leaf index 0 (wive_bvh8_impl.h:84-137) -- a real triangle, tested once more; the kernels must too.
+    rng = np.random.default_rng(17)
+    sgn = rng.choice(np.float32([-1.0, 1.0]), (3, 2000))
+    s = (rng.random(2000, np.float32) * 4 + np.float32(0.5)).astype(np.float32)
+    through = pa.scenes.pack_rays((-sgn * s).T, sgn.T.copy(), np.zeros(2000, np.float32), np.full(2000, 3.4028234663852886e38, np.float32))
+    return {"primary": prim, "diffuse": diff, "shadow": shad, "random": rnd, "through_origin": through}
 
 
 # (lanes per ray, refill threshold, LDS stack window): window 0 = automatic, a small window forces most of
