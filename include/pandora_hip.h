@@ -100,7 +100,9 @@ int pgpu_voxelize(const float* positions, size_t n_vertices, const uint32_t* ind
 
 /* ------------------------------------------------------------------ device context
  * One context per GPU, one process per GPU. Replaces the TaskGraph/LRU-cache plumbing the reference
- * threads through its builder (offline_batching_acceleration_structure.h:106-126). */
+ * threads through its builder (offline_batching_acceleration_structure.h:106-126). A context is not thread-safe, and its
+ * calls share work cursors and scratch buffers: two traces of one context must not be in flight at the same time, not
+ * even on different streams (queue them on one stream, or use one context per concurrent batch). */
 int pgpu_init(int device_id, pgpu_ctx** out);
 void pgpu_shutdown(pgpu_ctx*);
 const char* pgpu_last_error(const pgpu_ctx*);
