@@ -38,7 +38,7 @@ def main() -> None:
     ap.add_argument("--kind", choices=["closest", "any"], default="closest")
     ap.add_argument("--tri", choices=["moller-trumbore", "watertight"], default="moller-trumbore",
                     help="leaf test: the branch the reference compiles (triangle_intersect.cpp:425-462) or its watertight variant (:340-423)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 21)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 24, help="rays of the batch the CPU oracle traces (and the GPU result is compared on): the whole batch by default, ~20 s of CPU work")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
