@@ -893,3 +893,19 @@ void orc_film_resolve(const uint64_t* film, size_t n_pixels, float* rgb_out)
     for (size_t i = 0; i < n_pixels * 3; ++i)
         rgb_out[i] = (float)film[i] * 5.9604644775390625e-08f;
 }
+
+void orc_svdag_trace(const orc_svdag* d, int lanes, const float* rays, size_t n, unsigned char* out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        orc_ray r;
+        r.o[0] = rays[0 * n + i];
+        r.o[1] = rays[1 * n + i];
+        r.o[2] = rays[2 * n + i];
+        r.d[0] = rays[3 * n + i];
+        r.d[1] = rays[4 * n + i];
+        r.d[2] = rays[5 * n + i];
+        r.tnear = rays[6 * n + i];
+        r.tfar = rays[7 * n + i];
+        out[i] = (unsigned char)orc_svdag_intersect(d, &r, lanes);
+    }
+}

@@ -155,6 +155,9 @@ void orc_scene_trace(const orc_scene* s, int any_hit, int tri_mode, int svdag_la
 void orc_brute_trace(const orc_mesh* m, size_t n_tris, int tri_mode, const float* rays, size_t n,
     float* t, uint32_t* prim, int n_threads);
 
+/* Batch form of orc_svdag_intersect over rays [8][n] (SoA, as orc_bvh8_trace): out[i] = 0 / 1. */
+void orc_svdag_trace(const orc_svdag* d, int lanes, const float* rays, size_t n, unsigned char* out);
+
 /* Film: Sensor::addPixelContribution over a batch (graphics_core/sensor.cpp:36-49, sensor.h:29-35; the fixed-point type
  * is cnl::fixed_point<uint64_t, -24>, a dependency that is not in the container: restated from its definition, parity
  * unpinned). film: 3 u64 per pixel. */

@@ -359,6 +359,19 @@ unsigned ref_bvh8_inner(const orc_bvh8_node* n, const orc_ray* r, uint32_t kids[
 }
 
 int ref_svdag_intersect(const orc_svdag* d, const orc_ray* r) { return castDag(*d, *r) ? 1 : 0; }
+void ref_svdag_trace(const orc_svdag* d, const float* rays, size_t n, unsigned char* out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        orc_ray r;
+        for (int a = 0; a < 3; ++a) {
+            r.o[a] = rays[size_t(a) * n + i];
+            r.d[a] = rays[size_t(3 + a) * n + i];
+        }
+        r.tnear = rays[6 * n + i];
+        r.tfar = rays[7 * n + i];
+        out[i] = castDag(*d, r) ? 1 : 0;
+    }
+}
 
 void ref_bvh8_trace(const orc_bvh8* b, int any_hit, int tri_mode, const float* rays, size_t n,
     float* t, uint32_t* obj, float* u, float* v, uint32_t* anyhit)
