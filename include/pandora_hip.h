@@ -102,7 +102,13 @@ int pgpu_voxelize(const float* positions, size_t n_vertices, const uint32_t* ind
  * One context per GPU, one process per GPU. Replaces the TaskGraph/LRU-cache plumbing the reference
  * threads through its builder (offline_batching_acceleration_structure.h:106-126). A context is not thread-safe, and its
  * calls share work cursors and scratch buffers: two traces of one context must not be in flight at the same time, not
- * even on different streams (queue them on one stream, or use one context per concurrent batch). */
+ * even on different streams (queue them on one stream, or use one context per concurrent batch).
+ *
+ * Streams. Every call that takes `void* stream` queues its work on that hipStream_t; NULL means the context's own
+ * stream. That stream is a *blocking* stream (hipStreamDefault): it is ordered against the legacy null stream in both
+ * directions, so a caller whose other work runs on the null stream (torch's default stream has handle 0, which reads as
+ * NULL here) needs no events around library calls. A caller that passes one of its own streams gets plain stream
+ * order on it; work on other non-blocking streams must be ordered with events by the caller. */
 int pgpu_init(int device_id, pgpu_ctx** out);
 void pgpu_shutdown(pgpu_ctx*);
 const char* pgpu_last_error(const pgpu_ctx*);
@@ -127,7 +133,9 @@ int pgpu_upload_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint
  * two-level loop copies it into an HBM cache slot (hipMemcpyAsync on a copy stream, least recently used slot evicted)
  * when rays are parked at its batching point. pgpu_set_leaf_cache sets the HBM budget of that cache in bytes
  * (0 = room for every staged BVH); it must hold at least one BVH. Staged ids share the id space of uploaded ones but
- * are valid only as pgpu_leaf.bvh_id for pgpu_trace. */
+ * are valid only as pgpu_leaf.bvh_id for pgpu_trace: pgpu_trace_bvh8, pgpu_trace_leaves and pgpu_trace_leaf_records return
+ * PGPU_ERR_NO_SCENE on a context that holds staged BVHs. Staging another BVH (or pgpu_set_leaf_cache) empties the cache;
+ * it is rebuilt, with slots that fit the largest staged image, by the next pgpu_trace. */
 int pgpu_stage_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_leaf_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
 int pgpu_set_leaf_cache(pgpu_ctx*, size_t bytes);
@@ -244,7 +252,7 @@ int pgpu_route_merge(pgpu_ctx*, int kind, const float* results, const uint32_t* 
  * the format, undefined in the reference) or pixel[i] >= n_pixels. Negative channels wrap (adding them subtracts).
  * Integer adds commute: the film does not depend on the order of the contributions, and the films of several GPUs
  * sum with an integer all-reduce. All pointers are device memory; the call only enqueues work on `stream` (NULL =
- * the context's stream). pgpu_film_resolve is Sensor::Pixel -> vec3 (sensor.cpp:96-99): rgb_out[3 i + c] =
+ * the context's stream). n <= 2^30 contributions per call, like the trace entry points. pgpu_film_resolve is Sensor::Pixel -> vec3 (sensor.cpp:96-99): rgb_out[3 i + c] =
  * float(film[3 i + c]) * 2^-24. */
 int pgpu_film_add(pgpu_ctx*, unsigned long long* film, size_t n_pixels, const uint32_t* pixel, const float* r, const float* g,
     const float* b, size_t n, void* stream);

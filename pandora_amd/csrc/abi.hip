@@ -8,9 +8,9 @@
 
 using namespace pandora_hip;
 
-namespace {
+namespace pandora_hip {
 
-int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+int fail(pgpu_ctx* c, int code, const char* what, hipError_t e)
 {
     if (c) {
         c->err = what;
@@ -20,27 +20,6 @@ int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
         }
     }
     return code;
-}
-
-#define HIP_TRY(ctx, call)                                       \
-    do {                                                         \
-        hipError_t e_ = (call);                                  \
-        if (e_ != hipSuccess)                                    \
-            return fail((ctx), PGPU_ERR_HIP, #call, e_);         \
-    } while (0)
-
-template <typename T>
-int uploadArray(pgpu_ctx* c, const T* host, size_t n, T** dev)
-{
-    *dev = nullptr;
-    void* p = nullptr;
-    const size_t bytes = std::max<size_t>(n * sizeof(T), 16);
-    HIP_TRY(c, hipMalloc(&p, bytes));
-    c->owned.push_back(p);
-    if (n)
-        HIP_TRY(c, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
-    *dev = static_cast<T*>(p);
-    return PGPU_OK;
 }
 
 int ensure(pgpu_ctx* c, DeviceBuffer& b, size_t bytes)
@@ -63,11 +42,50 @@ int syncBvhTable(pgpu_ctx* c)
     if (c->bvhTableCap < c->bvhs.size()) {
         if (c->bvhTable)
             HIP_TRY(c, hipFree(c->bvhTable));
+        c->bvhTable = nullptr;
         c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
         HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
     }
     HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
     c->bvhTableDirty = false;
+    return PGPU_OK;
+}
+
+// Staged BVHs lose their slots and the arena is freed: the cache is rebuilt (empty) at the next pgpu_trace.
+int dropLeafCache(pgpu_ctx* c)
+{
+    if (c->cacheArena || !c->slots.empty())
+        HIP_TRY(c, hipDeviceSynchronize());
+    for (size_t i = 0; i < c->bvhs.size(); ++i)
+        if (i < c->staged.size() && c->staged[i].host) {
+            c->staged[i].slot = -1;
+            c->bvhs[i].nodes = nullptr;
+            c->bvhs[i].tris = nullptr;
+        }
+    c->slots.clear();
+    if (c->cacheArena)
+        HIP_TRY(c, hipFree(c->cacheArena));
+    c->cacheArena = nullptr;
+    c->slotBytes = 0;
+    c->bvhTableDirty = true;
+    return PGPU_OK;
+}
+
+} // namespace pandora_hip
+
+namespace {
+
+template <typename T>
+int uploadArray(pgpu_ctx* c, const T* host, size_t n, T** dev)
+{
+    *dev = nullptr;
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    HIP_TRY(c, hipMalloc(&p, bytes));
+    c->owned.push_back(p);
+    if (n)
+        HIP_TRY(c, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<T*>(p);
     return PGPU_OK;
 }
 
@@ -188,7 +206,7 @@ int pgpu_init(int device_id, pgpu_ctx** out)
     c->device = device_id;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess)
-        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamDefault); // blocking: ordered against the legacy null stream (header: "streams")
     if (e == hipSuccess)
         e = hipEventCreate(&c->ev0);
     if (e == hipSuccess)
@@ -385,7 +403,7 @@ int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const ui
     c->staged.resize(c->bvhs.size());
     c->bvhTableDirty = true;
     *bvh_id = uint32_t(c->bvhs.size() - 1);
-    return PGPU_OK;
+    return syncBvhTable(c); // the device table is complete after every upload: trace calls need not allocate for it
 }
 
 int pgpu_stage_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
@@ -399,6 +417,11 @@ int pgpu_stage_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uin
     const int rc = prepareBvh8(c, "pgpu_stage_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, tris, d);
     if (rc != PGPU_OK)
         return rc;
+    // The cache's slots were sized for the images staged so far: start over (it is rebuilt at the next pgpu_trace), or
+    // an image larger than a slot would overrun it.
+    const int rd = dropLeafCache(c);
+    if (rd != PGPU_OK)
+        return rd;
     StagedBvh s;
     s.nodeBytes = (n_nodes * 256 + 255) & ~size_t(255);
     s.triBytes = (tris.size() * 4 + 255) & ~size_t(255);
@@ -421,24 +444,10 @@ int pgpu_set_leaf_cache(pgpu_ctx* c, size_t bytes)
     if (!c)
         return PGPU_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipDeviceSynchronize());
-    // the cache is rebuilt (empty) at the next pgpu_trace
-    for (StagedBvh& s : c->staged)
-        if (s.host && s.slot >= 0) {
-            s.slot = -1;
-        }
-    for (size_t i = 0; i < c->bvhs.size(); ++i)
-        if (i < c->staged.size() && c->staged[i].host) {
-            c->bvhs[i].nodes = nullptr;
-            c->bvhs[i].tris = nullptr;
-        }
-    c->slots.clear();
-    if (c->cacheArena)
-        HIP_TRY(c, hipFree(c->cacheArena));
-    c->cacheArena = nullptr;
-    c->slotBytes = 0;
+    const int rc = dropLeafCache(c);
+    if (rc != PGPU_OK)
+        return rc;
     c->cacheBudget = bytes;
-    c->bvhTableDirty = true;
     return PGPU_OK;
 }
 

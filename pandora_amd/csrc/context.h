@@ -82,8 +82,32 @@ struct pgpu_ctx {
 };
 
 namespace pandora_hip {
+// Shared by every translation unit of the C ABI (defined in abi.hip).
+// fail: records the message pgpu_last_error returns and hands back `code`.
+int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+// ensure: grows a scratch buffer (never shrinks); the old contents are lost.
+int ensure(pgpu_ctx* c, DeviceBuffer& b, size_t bytes);
+// syncBvhTable: re-uploads the device copy of c->bvhs if an entry changed since the last upload.
+int syncBvhTable(pgpu_ctx* c);
+// dropLeafCache: waits for the device, empties and frees the HBM cache of staged BVHs (it is rebuilt at the next pgpu_trace).
+int dropLeafCache(pgpu_ctx* c);
+inline size_t alignUp(size_t v) { return (v + 255) & ~size_t(255); }
+inline uint32_t deepestBvh(const pgpu_ctx* c)
+{
+    uint32_t d = 0;
+    for (const Bvh8Dev& b : c->bvhs)
+        d = b.depth > d ? b.depth : d;
+    return d;
+}
 // Fills the stack window / spill fields of a bottom-level launch for trees of the given depth and returns
 // the grid size for n_work items (abi.hip).
 int readKernelStats(pgpu_ctx* c);
 int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
 }
+
+#define HIP_TRY(ctx, call)                                            \
+    do {                                                              \
+        hipError_t e_ = (call);                                       \
+        if (e_ != hipSuccess)                                         \
+            return pandora_hip::fail((ctx), PGPU_ERR_HIP, #call, e_); \
+    } while (0)

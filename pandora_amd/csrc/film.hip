@@ -12,18 +12,6 @@ using namespace pandora_hip;
 
 namespace {
 
-int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
-{
-    if (c) {
-        c->err = what;
-        if (e != hipSuccess) {
-            c->err += ": ";
-            c->err += hipGetErrorString(e);
-        }
-    }
-    return code;
-}
-
 // one channel of Pixel(color): float -> 40.24. Negative values wrap (two's complement: adding them subtracts).
 __device__ __forceinline__ unsigned long long toFixed(float c) { return (unsigned long long)(long long)(c * 16777216.0f); }
 
@@ -49,8 +37,8 @@ __global__ __launch_bounds__(256) void filmAddKernel(unsigned long long* film, u
 
 __global__ __launch_bounds__(256) void filmResolveKernel(const unsigned long long* film, uint32_t nValues, float* out)
 {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nValues; i += stride)
+    const size_t stride = size_t(gridDim.x) * blockDim.x; // (nValues is close to 2^32 for the largest film: 64-bit index)
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nValues; i += stride)
         out[i] = float(film[i]) * 5.9604644775390625e-08f; // sensor.cpp:96-99 (2^-24)
 }
 
@@ -63,8 +51,8 @@ int pgpu_film_add(pgpu_ctx* c, unsigned long long* film, size_t n_pixels, const 
 {
     if (!c)
         return PGPU_ERR_INVALID;
-    if (!film || n_pixels == 0 || n_pixels > 0x55555555u || n > 0xFFFFFFFFu || (n && (!pixel || !r || !g || !b)))
-        return fail(c, PGPU_ERR_INVALID, "pgpu_film_add: null argument, empty film or more than 2^32 contributions");
+    if (!film || n_pixels == 0 || n_pixels > 0x55555555u || n > 0x3FFFFFFFu || (n && (!pixel || !r || !g || !b)))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_film_add: null argument, empty film or more than 2^30 contributions");
     if (n == 0)
         return PGPU_OK;
     if (hipSetDevice(c->device) != hipSuccess)

@@ -7,40 +7,6 @@ using namespace pandora_hip;
 
 namespace {
 
-int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
-{
-    if (c) {
-        c->err = what;
-        if (e != hipSuccess) {
-            c->err += ": ";
-            c->err += hipGetErrorString(e);
-        }
-    }
-    return code;
-}
-
-#define HIP_TRY(ctx, call)                               \
-    do {                                                 \
-        hipError_t e_ = (call);                          \
-        if (e_ != hipSuccess)                            \
-            return fail((ctx), PGPU_ERR_HIP, #call, e_); \
-    } while (0)
-
-int ensureBuf(pgpu_ctx* c, DeviceBuffer& b, size_t bytes)
-{
-    if (b.bytes >= bytes)
-        return PGPU_OK;
-    if (b.ptr)
-        HIP_TRY(c, hipFree(b.ptr));
-    b.ptr = nullptr;
-    b.bytes = 0;
-    HIP_TRY(c, hipMalloc(&b.ptr, bytes));
-    b.bytes = bytes;
-    return PGPU_OK;
-}
-
-size_t alignUp(size_t v) { return (v + 255) & ~size_t(255); }
-
 uint32_t gridFor(const pgpu_ctx* c, size_t n) { return uint32_t(std::max<size_t>(1, std::min<size_t>((n + 255) / 256, size_t(c->numCUs) * 8))); }
 
 } // namespace
@@ -67,7 +33,7 @@ int pgpu_route_pack(pgpu_ctx* c, const pgpu_rays* rays, const float* t_state, co
             return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: null ray array");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
-    int rc = ensureBuf(c, c->blockWork, alignUp(n_active * 4) + 1024);
+    int rc = ensure(c, c->blockWork, alignUp(n_active * 4) + 1024);
     if (rc != PGPU_OK)
         return rc;
     // the two small counter arrays sit behind the work-item scratch
@@ -107,6 +73,8 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
         return PGPU_OK;
     if (c->bvhs.empty())
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no bottom-level BVH is resident");
+    if (c->nStaged > 0)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
     // scratch: SoA rays 8k, t/u/v 3k, obj/leaf/any 3k, workLeaf, sorted workRay/workBvh/workLeaf 3k, per-leaf count/start/fill, total
@@ -120,7 +88,7 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
     const size_t oSoa = carve(k * 32), oT = carve(k * 4), oU = carve(k * 4), oV = carve(k * 4), oObj = carve(k * 4), oLeaf = carve(k * 4), oAny = carve(k * 4);
     const size_t oWl = carve(k * 4), oSr = carve(k * 4), oSb = carve(k * 4), oSl = carve(k * 4);
     const size_t oCnt = carve(nl * 4), oStart = carve(nl * 4), oFill = carve(nl * 4), oTotal = carve(256);
-    int rc = ensureBuf(c, c->routeWork, off);
+    int rc = ensure(c, c->routeWork, off);
     if (rc != PGPU_OK)
         return rc;
     unsigned char* wb = static_cast<unsigned char*>(c->routeWork.ptr);
@@ -131,15 +99,10 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
              *sl = reinterpret_cast<uint32_t*>(wb + oSl);
     uint32_t *cnt = reinterpret_cast<uint32_t*>(wb + oCnt), *start = reinterpret_cast<uint32_t*>(wb + oStart), *fill = reinterpret_cast<uint32_t*>(wb + oFill),
              *total = reinterpret_cast<uint32_t*>(wb + oTotal);
-    if (c->bvhTableDirty) {
-        if (c->bvhTableCap < c->bvhs.size()) {
-            if (c->bvhTable)
-                HIP_TRY(c, hipFree(c->bvhTable));
-            c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
-        }
-        HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
-        c->bvhTableDirty = false;
+    {
+        const int rt = syncBvhTable(c);
+        if (rt != PGPU_OK)
+            return rt;
     }
     const uint32_t blocks = gridFor(c, k);
     const bool closest = kind == PGPU_CLOSEST;
@@ -172,9 +135,7 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
     ba.chunk = c->chunk;
     ba.init_miss = 0;
     ba.stats = c->stats ? c->statsDev : nullptr;
-    uint32_t deepest = 0;
-    for (const Bvh8Dev& b : c->bvhs)
-        deepest = std::max(deepest, b.depth);
+    const uint32_t deepest = deepestBvh(c);
     // every record names a valid leaf when it comes from pgpu_route_pack; a foreign record with a bad leaf id would leave
     // a hole at the end of the sorted list, so mark the tail as "no bvh" first
     HIP_TRY(c, hipMemsetAsync(sb, 0xFF, k * 4, stream));

@@ -10,25 +10,6 @@ using namespace pandora_hip;
 
 namespace {
 
-int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
-{
-    if (c) {
-        c->err = what;
-        if (e != hipSuccess) {
-            c->err += ": ";
-            c->err += hipGetErrorString(e);
-        }
-    }
-    return code;
-}
-
-#define HIP_TRY(ctx, call)                               \
-    do {                                                 \
-        hipError_t e_ = (call);                          \
-        if (e_ != hipSuccess)                            \
-            return fail((ctx), PGPU_ERR_HIP, #call, e_); \
-    } while (0)
-
 template <typename T>
 int uploadOwned(pgpu_ctx* c, const T* host, size_t n, T** dev)
 {
@@ -40,21 +21,6 @@ int uploadOwned(pgpu_ctx* c, const T* host, size_t n, T** dev)
     *dev = static_cast<T*>(p);
     return PGPU_OK;
 }
-
-int ensureBuf(pgpu_ctx* c, DeviceBuffer& b, size_t bytes)
-{
-    if (b.bytes >= bytes)
-        return PGPU_OK;
-    if (b.ptr)
-        HIP_TRY(c, hipFree(b.ptr));
-    b.ptr = nullptr;
-    b.bytes = 0;
-    HIP_TRY(c, hipMalloc(&b.ptr, bytes));
-    b.bytes = bytes;
-    return PGPU_OK;
-}
-
-size_t alignUp(size_t v) { return (v + 255) & ~size_t(255); }
 
 // Builds the (empty) HBM cache for staged BVHs: equal slots, each large enough for the largest staged image.
 int ensureLeafCache(pgpu_ctx* c)
@@ -89,7 +55,7 @@ int ensureLeafCache(pgpu_ctx* c)
 
 // Makes staged BVH `id` resident (no-op if it is); `pinned` marks the slots the current launch group needs.
 // Copies run on the copy stream, behind the last launch that read the slot being recycled.
-int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* copied)
+int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* copied, std::vector<uint32_t>& evicted)
 {
     StagedBvh& s = c->staged[id];
     if (s.slot >= 0) {
@@ -104,10 +70,11 @@ int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* c
     if (victim < 0)
         return fail(c, PGPU_ERR_INVALID, "leaf cache: no free slot (internal)");
     CacheSlot& slot = c->slots[size_t(victim)];
-    if (slot.bvh >= 0) { // evict (CachedBVH::doEvict)
+    if (slot.bvh >= 0) { // evict (CachedBVH::doEvict): the device table entry is nulled too, so a work item that names it is dropped
         c->staged[size_t(slot.bvh)].slot = -1;
         c->bvhs[size_t(slot.bvh)].nodes = nullptr;
         c->bvhs[size_t(slot.bvh)].tris = nullptr;
+        evicted.push_back(uint32_t(slot.bvh));
     }
     if (slot.lastLaunch >= 0)
         HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->launchEvents[size_t(slot.lastLaunch)], 0));
@@ -277,17 +244,9 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         return PGPU_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     {
-        // syncBvhTable lives in abi.hip; re-upload here if a BVH was added since the last trace
-        if (c->bvhTableDirty) {
-            if (c->bvhTableCap < c->bvhs.size()) {
-                if (c->bvhTable)
-                    HIP_TRY(c, hipFree(c->bvhTable));
-                c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
-                HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
-            }
-            HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
-            c->bvhTableDirty = false;
-        }
+        const int rt = syncBvhTable(c);
+        if (rt != PGPU_OK)
+            return rt;
     }
     hipStream_t stream = (mem == PGPU_MEM_DEVICE && stream_) ? static_cast<hipStream_t>(stream_) : c->stream;
     const bool wantVisits = hits && hits->visits;
@@ -309,7 +268,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         oRays = carve(n * 8 * 4);
         oHits = carve(n * 7 * 4);
     }
-    int rc = ensureBuf(c, c->work, off);
+    int rc = ensure(c, c->work, off);
     if (rc != PGPU_OK)
         return rc;
     unsigned char* wb = static_cast<unsigned char*>(c->work.ptr);
@@ -405,9 +364,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ba.cursor = c->cursor;
     ba.chunk = c->chunk;
     ba.init_miss = 0;
-    uint32_t deepest = 0;
-    for (const Bvh8Dev& b : c->bvhs)
-        deepest = std::max(deepest, b.depth);
+    const uint32_t deepest = deepestBvh(c);
     ba.stats = c->stats ? c->statsDev : nullptr;
 
     const bool streaming = c->nStaged > 0;
@@ -486,7 +443,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                                 break; // the cache is full of BVHs this launch needs: launch, then go on
                             ++pinnedCount;
                             bool moved = false;
-                            rc = makeResident(c, id, pinned, &moved);
+                            rc = makeResident(c, id, pinned, &moved, movedIds);
                             if (rc != PGPU_OK)
                                 return rc;
                             copied = copied || moved;
@@ -656,19 +613,16 @@ int pgpu_trace_leaves(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
         return PGPU_OK;
     if (c->bvhs.empty())
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaves: no bottom-level BVH is resident");
+    if (c->nStaged > 0)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaves: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->bvhTableDirty) {
-        if (c->bvhTableCap < c->bvhs.size()) {
-            if (c->bvhTable)
-                HIP_TRY(c, hipFree(c->bvhTable));
-            c->bvhTableCap = std::max<size_t>(64, c->bvhs.size() * 2);
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bvhTable), c->bvhTableCap * sizeof(Bvh8Dev)));
-        }
-        HIP_TRY(c, hipMemcpy(c->bvhTable, c->bvhs.data(), c->bvhs.size() * sizeof(Bvh8Dev), hipMemcpyHostToDevice));
-        c->bvhTableDirty = false;
+    {
+        const int rt = syncBvhTable(c);
+        if (rt != PGPU_OK)
+            return rt;
     }
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
-    int rc = ensureBuf(c, c->blockWork, alignUp(n_work * 4));
+    int rc = ensure(c, c->blockWork, alignUp(n_work * 4));
     if (rc != PGPU_OK)
         return rc;
     uint32_t* dWorkBvh = static_cast<uint32_t*>(c->blockWork.ptr);
@@ -700,9 +654,7 @@ int pgpu_trace_leaves(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
     ba.chunk = c->chunk;
     ba.init_miss = 0;
     ba.stats = c->stats ? c->statsDev : nullptr;
-    uint32_t deepest = 0;
-    for (const Bvh8Dev& b : c->bvhs)
-        deepest = std::max(deepest, b.depth);
+    const uint32_t deepest = deepestBvh(c);
     HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
     uint32_t blocks = 1;
     rc = planBvh8Launch(c, deepest, n_work, ba, &blocks);

@@ -1,8 +1,10 @@
 """GPU parity of leaves streamed from host memory (BASELINE config 5): whatever the size of the HBM leaf cache, the
-two-level loop must return what it returns with every leaf resident (bit-exact, counters included)."""
+two-level loop must return what the CPU oracle returns for the same two-level scene (bit-exact, counters included) --
+and therefore what it returns with every leaf resident."""
 import numpy as np
 import pytest
 
+import oracle_binding as ob
 import pandora_amd as pa
 
 pytestmark = pytest.mark.gpu
@@ -10,6 +12,18 @@ pytestmark = pytest.mark.gpu
 
 def _bits(a):
     return np.asarray(a).view(np.uint32)
+
+
+def _oracle(tl, mesh, rays):
+    """{kind: (results, counters)} from the CPU oracle, shaped like Context.trace's return value."""
+    scene = ob.scene_from_two_level(tl, mesh)
+    out = {}
+    for kind in (pa.capi.CLOSEST, pa.capi.ANY):
+        res = scene.trace(rays, any_hit=(kind == pa.capi.ANY), threads=8)
+        cnt = dict(res["counters"])
+        cnt["rounds"] = int(res["visits"].max())  # a ray pauses once per round, so the longest ray sets the round count
+        out[kind] = (res, cnt)
+    return out
 
 
 def _rays(mesh):
@@ -26,10 +40,7 @@ def test_streamed_leaves_match_resident(svdag):
     mesh = pa.scenes.g_small()
     tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=svdag)
     rays = _rays(mesh)
-    ref_ctx = pa.accel.Context(0)
-    tl.upload(ref_ctx, ref_ctx.upload_mesh(mesh.pos, mesh.idx))
-    want = {k: ref_ctx.trace(rays, kind=k) for k in (pa.capi.CLOSEST, pa.capi.ANY)}
-    ref_ctx.close()
+    want = _oracle(tl, mesh, rays)
 
     ctx = pa.accel.Context(0)
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=True)
@@ -64,5 +75,54 @@ def test_staged_bvh_cannot_be_traced_single_level():
     bid = ctx.stage_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
     with pytest.raises(pa.capi.PandoraError) as e:
         ctx.trace_bvh8(bid, _rays(mesh))
+    assert e.value.code == pa.capi.ERR_NO_SCENE
+    ctx.close()
+
+
+def test_bvh_staged_after_a_trace_gets_a_cache_that_fits():
+    """A BVH staged after the first pgpu_trace can be larger than the cache slots that trace sized: the cache has to be
+    rebuilt, or the copy overruns its slot."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    mesh = pa.scenes.g_small()
+    rays = _rays(mesh)
+    small = pa.accel.build_two_level(mesh.pos, mesh.idx, 48, svdag_res=0)
+    large = pa.accel.build_two_level(mesh.pos, mesh.idx, 500, svdag_res=16)
+    assert max(b.n_nodes for b in large.bvhs) > max(b.n_nodes for b in small.bvhs)
+    ctx = pa.accel.Context(0)
+    mid = ctx.upload_mesh(mesh.pos, mesh.idx)
+    for tl in (small, large):  # the second upload stages bigger images into the same context and replaces the top level
+        tl.upload(ctx, mid, streamed=True)
+        want = _oracle(tl, mesh, rays)
+        for kind in (pa.capi.CLOSEST, pa.capi.ANY):
+            got, cnt = ctx.trace(rays, kind=kind)
+            exp, ecnt = want[kind]
+            for k in (("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")):
+                assert np.array_equal(_bits(got[k]), _bits(exp[k])), k
+            assert cnt["leaf_visits"] == ecnt["leaf_visits"] and cnt["svdag_culled"] == ecnt["svdag_culled"]
+    ctx.close()
+
+
+def test_sharded_building_blocks_refuse_staged_contexts():
+    """pgpu_trace_leaves / pgpu_trace_leaf_records do not stream: with staged BVHs in the context they must refuse rather
+    than walk a cache slot that may hold another BVH's image."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    mesh = pa.scenes.g_small()
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64)
+    ctx = pa.accel.Context(0)
+    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=True)
+    dev = torch.device("cuda", 0)
+    rays = torch.from_numpy(_rays(mesh)).to(dev)
+    n = rays.shape[1]
+    hits = {k: torch.zeros(n, dtype=torch.float32 if k in ("t", "u", "v") else torch.int32, device=dev) for k in ("t", "obj", "leaf", "u", "v")}
+    work = torch.zeros(n, dtype=torch.int32, device=dev)
+    with pytest.raises(pa.capi.PandoraError) as e:
+        ctx.trace_leaves(pa.capi.CLOSEST, pa.capi.TRI_MT, rays, work, work, n, hits)
+    assert e.value.code == pa.capi.ERR_NO_SCENE
+    with pytest.raises(pa.capi.PandoraError) as e:
+        ctx.trace_leaf_records(pa.capi.CLOSEST, pa.capi.TRI_MT, torch.zeros(9 * 4, device=dev), 4, torch.zeros(16, device=dev))
     assert e.value.code == pa.capi.ERR_NO_SCENE
     ctx.close()
