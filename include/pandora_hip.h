@@ -202,6 +202,21 @@ typedef struct {
 int pgpu_trace_bvh8(pgpu_ctx*, uint32_t bvh_id, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
     const pgpu_hits* hits, uint32_t* any_hit, void* stream);
 
+/* pgpu_trace_bvh8 for callers that cannot allocate. No counterpart in the reference: it exists for callers that cannot call
+ * hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation. Same kernels and
+ * bit-identical results as pgpu_trace_bvh8 with PGPU_MEM_DEVICE (ray and result arrays are device memory; stream as above),
+ * but the kernels' scratch (work cursors + the overflow of the per-ray traversal stacks) is a static device array of
+ * PGPU_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends. The call makes no hipMalloc /
+ * hipFree. Limits: n <= PGPU_NOALLOC_MAX_RAYS (larger batches are rejected with PGPU_ERR_INVALID); on trees whose stack
+ * overflow does not fit the static array at full occupancy the grid is made smaller (never wrong, only slower); the bvh
+ * must have been uploaded with pgpu_upload_bvh8 (which also brings the device BVH table up to date -- if a BVH was staged
+ * since, the call returns PGPU_ERR_NO_SCENE rather than allocate). All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU race, whatever their contexts or streams. */
+#define PGPU_NOALLOC_MAX_RAYS 0x3FFFFFFFu
+#define PGPU_NOALLOC_SCRATCH_BYTES (256u + (64u << 20))
+int pgpu_trace_bvh8_noalloc(pgpu_ctx*, uint32_t bvh_id, int kind, int tri_mode, const pgpu_rays* rays, size_t n,
+    const pgpu_hits* hits, uint32_t* any_hit, void* stream);
+
 /* OfflineBatchingAccelerationStructure::intersect / intersectAny (offline_batching...h:406-437)
  * driven to completion for the whole batch: top-level traversal, SVDAG early-out, parking at batching
  * points, per-leaf bottom-level traversal, resume -- until every ray has exited. */

@@ -339,6 +339,17 @@ class Context:
             _check(self._L.pgpu_trace_bvh8(self._h, bvh_id, kind, tri_mode, C.byref(r), n, mem, None, capi.ptr(out["hit"]), stream), self._h)
         return out
 
+    def trace_bvh8_noalloc(self, bvh_id: int, rays, out: dict, kind: int = capi.CLOSEST, tri_mode: int = capi.TRI_MT, stream: int = 0):
+        """pgpu_trace_bvh8_noalloc: device tensors only, `out` allocated by the caller; the library allocates nothing."""
+        r, n = self._rays_struct(rays)
+        assert self._is_torch(rays)
+        if kind == capi.CLOSEST:
+            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), 0)
+            _check(self._L.pgpu_trace_bvh8_noalloc(self._h, bvh_id, kind, tri_mode, C.byref(r), n, C.byref(h), None, stream), self._h)
+        else:
+            _check(self._L.pgpu_trace_bvh8_noalloc(self._h, bvh_id, kind, tri_mode, C.byref(r), n, None, capi.ptr(out["hit"]), stream), self._h)
+        return out
+
     def trace(self, rays, kind: int = capi.CLOSEST, tri_mode: int = capi.TRI_MT, out=None, stream: int = 0):
         """Two-level trace through the uploaded top-level BVH4. Returns (results, counters dict)."""
         r, n = self._rays_struct(rays)

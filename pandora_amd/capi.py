@@ -87,6 +87,7 @@ SYMBOLS = {
     "pgpu_upload_svdags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "pgpu_upload_top_bvh4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),
     "pgpu_trace_bvh8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.c_int, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
+    "pgpu_trace_bvh8_noalloc": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
     "pgpu_trace": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.c_int, C.POINTER(Hits), C.c_void_p, C.POINTER(Counters), C.c_void_p]),
     "pgpu_ray_state_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
     "pgpu_top_episode": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Rays), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -156,7 +156,7 @@ int readKernelStats(pgpu_ctx* c)
     return PGPU_OK;
 }
 
-int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks)
+void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks)
 {
     const uint32_t need = stackEntriesForDepth(depth);
     const uint32_t window = stackWindow(need, c->stackWindow);
@@ -175,7 +175,13 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a,
     const uint32_t maxBlocks = uint32_t(c->numCUs) * blocksPerCU(c->blocksPerCU, window, lanes);
     const uint32_t wantBlocks = uint32_t((n_work + 2 * raysPerBlock - 1) / (2 * raysPerBlock));
     *blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
+}
+
+int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks)
+{
+    planBvh8LaunchShape(c, depth, n_work, a, blocks);
     if (a.spill_entries) {
+        const uint32_t raysPerBlock = 256u / a.lanes_per_ray;
         const size_t bytes = size_t(*blocks) * raysPerBlock * a.spill_entries * 8u;
         const int rc = ensure(c, c->spill, bytes);
         if (rc != PGPU_OK)
@@ -229,6 +235,10 @@ int pgpu_init(int device_id, pgpu_ctx** out)
         return PGPU_ERR_HIP;
     }
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (initStaticScratch(c) != PGPU_OK) {
+        pgpu_shutdown(c);
+        return PGPU_ERR_HIP;
+    }
     *out = c;
     return PGPU_OK;
 }

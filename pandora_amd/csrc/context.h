@@ -43,6 +43,7 @@ struct pgpu_ctx {
     uint32_t leafMin = 0; // 0: automatic
     int stackWindow = 0;     // LDS stack entries per ray, 0 = automatic
     DeviceBuffer spill;      // global overflow of the per-ray stacks
+    unsigned char* staticScratch = nullptr; // this device's copy of the static scratch array of noalloc.hip (resolved at pgpu_init)
 
     std::vector<HostMesh> meshes;
     std::vector<pandora_hip::Bvh8Dev> bvhs; // host mirror of the device table
@@ -103,6 +104,10 @@ inline uint32_t deepestBvh(const pgpu_ctx* c)
 // the grid size for n_work items (abi.hip).
 int readKernelStats(pgpu_ctx* c);
 int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
+// The same plan without the spill buffer: args.spill stays null, args.spill_entries says how many 8-byte entries every
+// ray group of every block needs (the caller provides the memory).
+void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
+int initStaticScratch(pgpu_ctx* c); // noalloc.hip
 }
 
 #define HIP_TRY(ctx, call)                                            \
