@@ -89,13 +89,17 @@ int uploadArray(pgpu_ctx* c, const T* host, size_t n, T** dev)
     return PGPU_OK;
 }
 
-// Longest chain of nested inner nodes; also validates every handle. Returns -1 on a malformed tree.
-int bvh8Depth(const unsigned char* nodes, size_t nNodes, size_t nIdx, uint32_t root)
+// Longest chain of nested inner nodes; also validates every handle reachable from the root and marks the nodes and leaf
+// slots the tree uses (the reference's allocators leave uninitialised gaps between their blocks,
+// contiguous_allocator_ts.h:151-198, so whatever is not reachable is not looked at). Returns -1 on a malformed tree.
+int bvh8Depth(const unsigned char* nodes, size_t nNodes, size_t nIdx, uint32_t root, std::vector<uint8_t>& nodeUsed, std::vector<uint8_t>& slotUsed)
 {
     struct E {
         uint32_t h;
         int d;
     };
+    nodeUsed.assign(nNodes, 0);
+    slotUsed.assign(nIdx, 0);
     std::vector<E> todo { { root, 0 } };
     int deepest = 0;
     size_t visited = 0;
@@ -106,14 +110,18 @@ int bvh8Depth(const unsigned char* nodes, size_t nNodes, size_t nIdx, uint32_t r
         if (flags == 2u) {
             if (index >= nNodes || ++visited > nNodes)
                 return -1;
+            nodeUsed[index] = 1;
             deepest = std::max(deepest, e.d + 1);
             const uint32_t* kids = reinterpret_cast<const uint32_t*>(nodes + size_t(index) * 256 + 192);
             for (int i = 0; i < 8; ++i)
                 if (kids[i] != 0u)
                     todo.push_back({ kids[i], e.d + 1 });
         } else if (flags & 4u) {
-            if (size_t(index) + ((flags & 3u) + 1u) > nIdx)
+            const uint32_t count = (flags & 3u) + 1u;
+            if (size_t(index) + count > nIdx)
                 return -1;
+            for (uint32_t k = 0; k < count; ++k)
+                slotUsed[index + k] = 1;
         } else {
             return -1; // reserved flag patterns 001 / 011 (000 = empty is skipped above)
         }
@@ -122,9 +130,11 @@ int bvh8Depth(const unsigned char* nodes, size_t nNodes, size_t nIdx, uint32_t r
 }
 
 // The kernel's fast slab test assumes min <= max and finite bounds for every present child.
-bool bvh8NeedsExact(const unsigned char* nodes, size_t nNodes)
+bool bvh8NeedsExact(const unsigned char* nodes, size_t nNodes, const std::vector<uint8_t>& nodeUsed)
 {
     for (size_t i = 0; i < nNodes; ++i) {
+        if (!nodeUsed[i])
+            continue;
         const float* f = reinterpret_cast<const float*>(nodes + i * 256);
         const uint32_t* kids = reinterpret_cast<const uint32_t*>(f) + 48;
         for (int c = 0; c < 8; ++c) {
@@ -354,13 +364,16 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
         return bad(PGPU_ERR_INVALID, "null or empty argument");
     if (n_nodes >= (1u << 29) || n_indices >= (1u << 29))
         return bad(PGPU_ERR_INVALID, "more than 2^29 nodes or leaf indices");
-    const int depth = bvh8Depth(static_cast<const unsigned char*>(nodes256), n_nodes, n_indices, root_handle);
+    std::vector<uint8_t> nodeUsed, slotUsed;
+    const int depth = bvh8Depth(static_cast<const unsigned char*>(nodes256), n_nodes, n_indices, root_handle, nodeUsed, slotUsed);
     if (depth < 0)
         return bad(PGPU_ERR_INVALID, "malformed tree (handle out of range or cycle)");
     if (7 * depth + 8 > 96) // the 96-entry traversal stack of wive_bvh8_impl.h:74-75
         return bad(PGPU_ERR_DEPTH, "more than 12 nested inner nodes");
     tris.assign((n_indices + 1) * 12, 0.0f); // (one zero record of padding: the pair kernel reads records two at a time)
     for (size_t s = 0; s < n_indices; ++s) {
+        if (!slotUsed[s])
+            continue; // a gap between allocator blocks: no leaf owns it, its record stays a degenerate zero triangle
         const uint32_t obj = leaf_indices[s];
         if (obj >= n_objs)
             return bad(PGPU_ERR_INVALID, "leaf index beyond the leaf-object table");
@@ -384,7 +397,7 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
     d.n_nodes = uint32_t(n_nodes);
     d.n_slots = uint32_t(n_indices);
     d.depth = uint32_t(depth);
-    d.needs_exact = bvh8NeedsExact(static_cast<const unsigned char*>(nodes256), n_nodes) ? 1u : 0u;
+    d.needs_exact = bvh8NeedsExact(static_cast<const unsigned char*>(nodes256), n_nodes, nodeUsed) ? 1u : 0u;
     return PGPU_OK;
 }
 

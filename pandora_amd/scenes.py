@@ -108,7 +108,17 @@ def cylinder(base, radius: float, height: float, seg: int, stacks: int) -> Mesh:
     return grid_patch(base, (0, 0, 0), (0, height, 0), seg, stacks, displace=disp)
 
 
+_UNIT_ICOSPHERES: dict = {}
+
+
 def icosphere(center, radius: float, level: int) -> Mesh:
+    if level not in _UNIT_ICOSPHERES:  # the subdivision is the same for every sphere of a level: do it once
+        _UNIT_ICOSPHERES[level] = _unit_icosphere(level)
+    v, f = _UNIT_ICOSPHERES[level]
+    return Mesh(np.asarray(center)[None, :] + radius * v, f)
+
+
+def _unit_icosphere(level: int):
     t = (1.0 + 5.0**0.5) / 2.0
     v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
                   [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
@@ -132,7 +142,7 @@ def icosphere(center, radius: float, level: int) -> Mesh:
             nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
         v, f = np.array(verts), np.array(nf)
     v = v / np.linalg.norm(v, axis=1, keepdims=True)
-    return Mesh(np.asarray(center)[None, :] + radius * v, f)
+    return v, f
 
 
 def _noise(s, t, seed: int, octaves: int = 4):

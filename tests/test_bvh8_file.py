@@ -141,3 +141,20 @@ def test_rejects_damaged_buffers_without_crashing(small):
         except pa.capi.PandoraError:
             pass
     assert ok < 400  # most corruptions of the header region must be noticed
+
+
+def test_reader_accepts_allocator_block_gaps():
+    """The reference's ContiguousAllocatorTS hands out blocks per thread, so the arrays it serialises contain uninitialised
+    gaps (contiguous_allocator_ts.h:151-198) and currentSize counts them. A file laid out that way must read back
+    verbatim, and the tree in it must trace like the dense one (the gaps are never looked at)."""
+    from bvh_helpers import with_gaps
+    z, mesh, hb, orc = ob.load_golden_bvh8()
+    dense = pa.accel.HostBvh8(np.ascontiguousarray(z["nodes"]), np.ascontiguousarray(z["leaf_idx"]), int(z["root"]), 0, np.ascontiguousarray(z["prim_ids"]))
+    gapped = with_gaps(dense)
+    assert gapped.n_nodes > dense.n_nodes and gapped.leaf_idx.size > dense.leaf_idx.size
+    back = pa.accel.bvh8_from_bytes(pa.accel.bvh8_to_bytes(gapped), gapped.prim_ids)
+    assert back.nodes.tobytes() == np.ascontiguousarray(gapped.nodes).tobytes() and np.array_equal(back.leaf_idx, gapped.leaf_idx)
+    assert back.root == gapped.root and back.depth == pa.accel.host_bvh8_depth(dense.nodes, dense.root)
+    got = ob.OracleBvh8.from_host(back, mesh).trace(z["rays"], threads=4)
+    for k in ("t", "obj", "u", "v"):
+        assert np.array_equal(got[k].view(np.uint32), z[f"tri0_{k}"].view(np.uint32)), k
