@@ -194,6 +194,7 @@ typedef struct {
     uint64_t leaf_loads, streamed_bytes; /* staged BVHs copied into the HBM leaf cache by the last pgpu_trace */
     uint64_t wave_steps, leaf_passes, refill_passes; /* kernel-loop diagnostics (stats enabled): wavefront iterations,
                                                        * those that ran the triangle code, those that fetched new rays */
+    uint64_t records_routed, exchange_bytes; /* pgpu_trace_sharded: records sent to other ranks; bytes sent + received */
 } pgpu_counters;
 
 /* WiVeBVH8::intersect / intersectAny over a batch (wive_bvh8_impl.h:57-201): single-level, in-core.
@@ -260,6 +261,48 @@ int pgpu_route_pack(pgpu_ctx*, const pgpu_rays* rays, const float* t_state, cons
 int pgpu_trace_leaf_records(pgpu_ctx*, int kind, int tri_mode, const float* records, size_t k, float* results, void* stream);
 int pgpu_route_merge(pgpu_ctx*, int kind, const float* results, const uint32_t* sent_slot, const uint32_t* sent_leaf, size_t k,
     const pgpu_hits* hits, uint32_t* any_hit, void* stream);
+
+/* ------------------------------------------------------------------ several GPUs: batching points sharded over HBM
+ * (BASELINE configs[3]). One process and one context per GPU. Every rank uploads the top level and the SVDAGs
+ * whole and the bottom-level BVHs of the batching points it owns (the others are PGPU_NO_BVH); rays stay on their home rank.
+ * The round loop of pgpu_trace then runs on every rank in lockstep: a ray parked at a batching point another rank owns
+ * travels there as a 36-byte record and its result ({t, obj, u, v} or {hit}) travels back -- an all-to-all of records in
+ * each direction per round, which replaces the reference's per-leaf MPMC queues and disk cache
+ * (stream/task_graph.h:130-156, task_graph.cpp:19-56; offline_batching...h:158-260). Rays parked at a batching point
+ * of their own rank never leave the SoA arrays. Results equal pgpu_trace's on one GPU bit for bit.
+ *
+ * pgpu_comm_unique_id: 128 bytes (an ncclUniqueId) that rank 0 makes and hands to the other ranks by any means.
+ * pgpu_comm_init:      joins the RCCL communicator of `world` ranks (collective: every rank calls it); world <= 64.
+ *                      RCCL is loaded at this call (dlopen librccl.so.1), not when the library is loaded.
+ * pgpu_comm_init_transport: the same with the three collectives supplied by the caller (MPI, a test harness, ...):
+ *     allgather_u32: every rank contributes n values, recv[r * n + i] = rank r's send[i];
+ *     exchange:      rows of row_bytes grouped by destination rank, send_counts[d] rows to rank d (in rank order), recv_counts[s]
+ *                    rows from rank s (in rank order); counts are host arrays of `world` entries, buffers device memory;
+ *     allreduce_u64: element-wise sum over ranks, in place.
+ *   All three work on device pointers, are ordered on `stream`, and return 0 or non-zero for failure.
+ * pgpu_set_leaf_owners: owner rank of every batching point (leaf slot order, host array). Needed before pgpu_trace_sharded.
+ * pgpu_trace_sharded: collective. Device arrays only (rays, hits, any_hit as in pgpu_trace with PGPU_MEM_DEVICE); n may
+ *                      differ between ranks (0 included). One host synchronisation per round (the matrix of record counts).
+ *                      counters additionally reports records_routed (records this rank sent to other ranks) and
+ *                      exchange_bytes (bytes this rank sent and received in all-to-alls, both directions).
+ * pgpu_film_allreduce: sums the u64 fixed-point films of all ranks in place (the integer all-reduce of SURVEY.md K8). */
+typedef struct {
+    void* user;
+    int (*allgather_u32)(void* user, const uint32_t* send, uint32_t* recv, size_t n, void* stream);
+    int (*exchange)(void* user, const void* send, const uint32_t* send_counts, void* recv, const uint32_t* recv_counts, size_t row_bytes, void* stream);
+    int (*allreduce_u64)(void* user, unsigned long long* buf, size_t n, void* stream);
+} pgpu_transport;
+int pgpu_comm_unique_id(void* out128);
+int pgpu_comm_init(pgpu_ctx*, int rank, int world, const void* unique_id128);
+int pgpu_comm_init_transport(pgpu_ctx*, int rank, int world, const pgpu_transport* transport);
+int pgpu_comm_destroy(pgpu_ctx*);
+/* Collective: runs every collective of the transport once on small known buffers and checks what comes back (with RCCL also a
+ * point-to-point message from the rank to itself). PGPU_OK, or PGPU_ERR_HIP with the failing step in pgpu_last_error. */
+int pgpu_comm_selftest(pgpu_ctx*);
+int pgpu_set_leaf_owners(pgpu_ctx*, const uint32_t* owner_of_leaf, size_t n_leaves);
+int pgpu_trace_sharded(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, size_t n, const pgpu_hits* hits, uint32_t* any_hit,
+    pgpu_counters* counters, void* stream);
+int pgpu_film_allreduce(pgpu_ctx*, unsigned long long* film, size_t n_pixels, void* stream);
 
 /* Film. Sensor::addPixelContribution (graphics_core/sensor.cpp:36-49) over a batch of contributions:
  * `film` holds three u64 per pixel in 40.24 fixed point (sensor.h:29-35), film[3 * pixel[i] + c] += fixed(rgb[i][c]).

@@ -406,6 +406,59 @@ class Context:
         _check(self._L.pgpu_route_merge(self._h, kind, capi.ptr(results), capi.ptr(sent_slot), capi.ptr(sent_leaf), k, C.byref(h) if h is not None else None,
                                         capi.ptr(any_hit), stream), self._h)
 
+    # -- several GPUs: batching points sharded over the ranks (pgpu_trace_sharded; one process and one context per GPU)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes (an ncclUniqueId) that rank 0 makes and hands to every other rank."""
+        buf = C.create_string_buffer(128)
+        rc = capi.lib().pgpu_comm_unique_id(buf)
+        if rc != capi.OK:
+            raise PandoraError(rc, "pgpu_comm_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """Joins the RCCL communicator (collective)."""
+        assert len(unique_id) == 128
+        _check(self._L.pgpu_comm_init(self._h, rank, world, unique_id), self._h)
+
+    def comm_init_transport(self, rank: int, world: int, transport):
+        """The collectives come from `transport` (an object with .struct(): capi.Transport, kept alive here)."""
+        self._transport = transport
+        self._transport_struct = transport.struct()
+        _check(self._L.pgpu_comm_init_transport(self._h, rank, world, C.byref(self._transport_struct)), self._h)
+
+    def comm_selftest(self):
+        """Every collective of the transport once, results checked (collective)."""
+        _check(self._L.pgpu_comm_selftest(self._h), self._h)
+
+    def comm_destroy(self):
+        _check(self._L.pgpu_comm_destroy(self._h), self._h)
+
+    def set_leaf_owners(self, owner_of_leaf):
+        o = np.ascontiguousarray(owner_of_leaf, np.uint32)
+        _check(self._L.pgpu_set_leaf_owners(self._h, o.ctypes.data, o.size), self._h)
+
+    def trace_sharded(self, rays, kind: int = capi.CLOSEST, tri_mode: int = capi.TRI_MT, out=None, stream: int = 0):
+        """pgpu_trace_sharded (collective; device tensors). Returns (results, counters dict) like trace()."""
+        r, n = self._rays_struct(rays)
+        assert self._is_torch(rays)
+        cnt = capi.Counters()
+        if kind == capi.CLOSEST:
+            if out is None:
+                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v", "visits")}
+            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), capi.ptr(out.get("visits")))
+            _check(self._L.pgpu_trace_sharded(self._h, kind, tri_mode, C.byref(r), n, C.byref(h), None, C.byref(cnt), stream), self._h)
+        else:
+            if out is None:
+                out = {"hit": self._alloc(rays, n, "u"), "visits": self._alloc(rays, n, "u")}
+            h = capi.Hits(0, 0, 0, 0, 0, capi.ptr(out.get("visits")))
+            _check(self._L.pgpu_trace_sharded(self._h, kind, tri_mode, C.byref(r), n, C.byref(h), capi.ptr(out["hit"]), C.byref(cnt), stream), self._h)
+        return out, {f: int(getattr(cnt, f)) for f, _ in capi.Counters._fields_}
+
+    def film_allreduce(self, film, stream: int = 0):
+        """Sums the int64 fixed-point films of all ranks in place (pgpu_film_allreduce)."""
+        _check(self._L.pgpu_film_allreduce(self._h, capi.ptr(film), int(film.numel() // 3), stream), self._h)
+
     def film_add(self, film, pixel, r, g, b, stream: int = 0):
         """Sensor::addPixelContribution over a batch (sensor.cpp:36-49). film: int64 device tensor [n_pixels, 3] (40.24
         fixed point); pixel: int32 device tensor [n]; r, g, b: float32 device tensors [n]. Enqueues on `stream`."""

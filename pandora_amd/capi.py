@@ -35,7 +35,16 @@ class Hits(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "rounds", "inner_visits", "leaf_pops", "tri_tests", "leaf_loads", "streamed_bytes", "wave_steps", "leaf_passes", "refill_passes")]
+    _fields_ = [(n, C.c_uint64) for n in ("svdag_tests", "svdag_culled", "leaf_visits", "rounds", "inner_visits", "leaf_pops", "tri_tests", "leaf_loads", "streamed_bytes", "wave_steps", "leaf_passes", "refill_passes", "records_routed", "exchange_bytes")]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allgather_u32", ALLGATHER_FN), ("exchange", EXCHANGE_FN), ("allreduce_u64", ALLREDUCE_FN)]
 
 
 class LeafObj(C.Structure):
@@ -105,6 +114,14 @@ SYMBOLS = {
     "pgpu_set_ray_layout": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_mesh_serialize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgpu_mesh_deserialize": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9),
+    "pgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pgpu_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pgpu_comm_init_transport": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Transport)]),
+    "pgpu_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pgpu_comm_selftest": (C.c_int, [C.c_void_p]),
+    "pgpu_set_leaf_owners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "pgpu_trace_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits), C.c_void_p, C.POINTER(Counters), C.c_void_p]),
+    "pgpu_film_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgpu_film_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgpu_film_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

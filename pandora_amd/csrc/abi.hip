@@ -259,6 +259,7 @@ void pgpu_shutdown(pgpu_ctx* c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    destroyComm(c);
     for (void* p : c->owned)
         (void)hipFree(p);
     if (c->bvhTable)
@@ -280,7 +281,7 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipEventDestroy(c->copyDone);
     if (c->copyStream)
         (void)hipStreamDestroy(c->copyStream);
-    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork })
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv })
         if (b->ptr)
             (void)hipFree(b->ptr);
     (void)hipEventDestroy(c->ev0);

@@ -28,6 +28,8 @@ struct CacheSlot {
     int lastLaunch = -1; // index into launchEvents: recorded on the compute stream after the last launch that read the slot
 };
 
+struct Comm;
+
 struct pgpu_ctx {
     int device = 0;
     int numCUs = 256;
@@ -69,6 +71,13 @@ struct pgpu_ctx {
     DeviceBuffer routeWork; // scratch of pgpu_trace_leaf_records
     unsigned long long* topCounters = nullptr; // SVDAG tests / culled of pgpu_top_episode calls (device)
 
+    // several GPUs (sharded_abi.hip)
+    Comm* comm = nullptr;
+    std::vector<uint32_t> leafOwnerHost;
+    uint32_t* leafOwnerDev = nullptr;       // owner rank per batching point
+    uint32_t* leafOwnerRemoteDev = nullptr; // the same with this rank's own points marked "no destination"
+    DeviceBuffer shardWork, shardSend, shardRecv;
+
     // streamed leaves
     std::vector<StagedBvh> staged;               // indexed by bvh id; host == nullptr for HBM-resident ones
     std::vector<pandora_hip::TopLeafDev> topLeavesHost;
@@ -108,6 +117,8 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& ar
 // ray group of every block needs (the caller provides the memory).
 void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
 int initStaticScratch(pgpu_ctx* c); // noalloc.hip
+int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream); // route_abi.hip
+void destroyComm(pgpu_ctx* c); // sharded_abi.hip
 }
 
 #define HIP_TRY(ctx, call)                                            \

@@ -11,72 +11,12 @@ uint32_t gridFor(const pgpu_ctx* c, size_t n) { return uint32_t(std::max<size_t>
 
 } // namespace
 
-extern "C" {
+namespace pandora_hip {
 
-int pgpu_route_pack(pgpu_ctx* c, const pgpu_rays* rays, const float* t_state, const uint32_t* active, const uint32_t* parked_leaf, size_t n_active,
-    const uint32_t* owner_of_leaf, uint32_t world, uint32_t* dest_counts_host, float* records, uint32_t* sent_slot, uint32_t* sent_leaf, void* stream_)
+// The owner side of one round: k received records through the batching points they name -> k results, same order.
+// (Arguments are validated by the callers.)
+int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream)
 {
-    if (!c || !dest_counts_host || (n_active && (!rays || !parked_leaf || !owner_of_leaf || !records || !sent_slot || !sent_leaf)))
-        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: null argument");
-    if (!c->haveTop)
-        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_route_pack: no top-level structure uploaded");
-    if (world == 0 || world > routeMaxRanks())
-        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: between 1 and 64 ranks");
-    if (n_active > 0x3FFFFFFFull)
-        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: batch too large");
-    std::memset(dest_counts_host, 0, world * sizeof(uint32_t));
-    if (n_active == 0)
-        return PGPU_OK;
-    const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, t_state ? t_state : rays->tfar };
-    for (const float* p : rp)
-        if (!p)
-            return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: null ray array");
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
-    int rc = ensure(c, c->blockWork, alignUp(n_active * 4) + 1024);
-    if (rc != PGPU_OK)
-        return rc;
-    // the two small counter arrays sit behind the work-item scratch
-    uint32_t* dCounts = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->blockWork.ptr) + c->blockWork.bytes - 1024);
-    uint32_t* dFill = dCounts + 64;
-    HIP_TRY(c, hipMemsetAsync(dCounts, 0, 512, stream));
-    const uint32_t blocks = gridFor(c, n_active);
-    HIP_TRY(c, launchRouteCount(parked_leaf, uint32_t(n_active), owner_of_leaf, c->top.n_leaves, world, dCounts, blocks, stream));
-    HIP_TRY(c, hipMemcpyAsync(dest_counts_host, dCounts, world * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(c, hipStreamSynchronize(stream));
-    uint32_t starts[64] = { 0 };
-    uint32_t run = 0;
-    for (uint32_t d = 0; d < world; ++d) {
-        starts[d] = run;
-        run += dest_counts_host[d];
-    }
-    if (run == 0)
-        return PGPU_OK;
-    HIP_TRY(c, launchRouteScatter(rp, active, parked_leaf, uint32_t(n_active), owner_of_leaf, c->top.n_leaves, world, starts, dFill, records, sent_slot,
-                   sent_leaf, blocks, stream));
-    return PGPU_OK;
-}
-
-int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, void* stream_)
-{
-    if (!c || (k && (!records || !results)))
-        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: null argument");
-    if (!c->haveTop)
-        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no top-level structure uploaded");
-    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
-        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: kind must be PGPU_CLOSEST or PGPU_ANY");
-    if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
-        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: unknown triangle test");
-    if (k > 0x3FFFFFFFull)
-        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: batch too large");
-    if (k == 0)
-        return PGPU_OK;
-    if (c->bvhs.empty())
-        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no bottom-level BVH is resident");
-    if (c->nStaged > 0)
-        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
     // scratch: SoA rays 8k, t/u/v 3k, obj/leaf/any 3k, workLeaf, sorted workRay/workBvh/workLeaf 3k, per-leaf count/start/fill, total
     const size_t nl = c->top.n_leaves;
     size_t off = 0;
@@ -146,11 +86,83 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
     rc = planBvh8Launch(c, deepest, k, ba, &nBlocks);
     if (rc != PGPU_OK)
         return rc;
-    HIP_TRY(c, hipEventRecord(c->ev0, stream));
     HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, nBlocks, stream));
-    HIP_TRY(c, hipEventRecord(c->ev1, stream));
     HIP_TRY(c, launchPackResults(uint32_t(k), t, obj, u, v, closest ? nullptr : any, results, blocks, stream));
     return PGPU_OK;
+}
+
+} // namespace pandora_hip
+
+extern "C" {
+
+int pgpu_route_pack(pgpu_ctx* c, const pgpu_rays* rays, const float* t_state, const uint32_t* active, const uint32_t* parked_leaf, size_t n_active,
+    const uint32_t* owner_of_leaf, uint32_t world, uint32_t* dest_counts_host, float* records, uint32_t* sent_slot, uint32_t* sent_leaf, void* stream_)
+{
+    if (!c || !dest_counts_host || (n_active && (!rays || !parked_leaf || !owner_of_leaf || !records || !sent_slot || !sent_leaf)))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: null argument");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_route_pack: no top-level structure uploaded");
+    if (world == 0 || world > routeMaxRanks())
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: between 1 and 64 ranks");
+    if (n_active > 0x3FFFFFFFull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: batch too large");
+    std::memset(dest_counts_host, 0, world * sizeof(uint32_t));
+    if (n_active == 0)
+        return PGPU_OK;
+    const float* rp[8] = { rays->ox, rays->oy, rays->oz, rays->dx, rays->dy, rays->dz, rays->tnear, t_state ? t_state : rays->tfar };
+    for (const float* p : rp)
+        if (!p)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_route_pack: null ray array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    int rc = ensure(c, c->blockWork, alignUp(n_active * 4) + 1024);
+    if (rc != PGPU_OK)
+        return rc;
+    // the two small counter arrays sit behind the work-item scratch
+    uint32_t* dCounts = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->blockWork.ptr) + c->blockWork.bytes - 1024);
+    uint32_t* dFill = dCounts + 64;
+    HIP_TRY(c, hipMemsetAsync(dCounts, 0, 512, stream));
+    const uint32_t blocks = gridFor(c, n_active);
+    HIP_TRY(c, launchRouteCount(parked_leaf, uint32_t(n_active), owner_of_leaf, c->top.n_leaves, world, dCounts, blocks, stream));
+    HIP_TRY(c, hipMemcpyAsync(dest_counts_host, dCounts, world * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    uint32_t starts[64] = { 0 };
+    uint32_t run = 0;
+    for (uint32_t d = 0; d < world; ++d) {
+        starts[d] = run;
+        run += dest_counts_host[d];
+    }
+    if (run == 0)
+        return PGPU_OK;
+    HIP_TRY(c, launchRouteScatter(rp, active, parked_leaf, uint32_t(n_active), owner_of_leaf, c->top.n_leaves, world, starts, dFill, records, sent_slot,
+                   sent_leaf, blocks, stream));
+    return PGPU_OK;
+}
+
+int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, void* stream_)
+{
+    if (!c || (k && (!records || !results)))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: null argument");
+    if (!c->haveTop)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no top-level structure uploaded");
+    if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: kind must be PGPU_CLOSEST or PGPU_ANY");
+    if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: unknown triangle test");
+    if (k > 0x3FFFFFFFull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaf_records: batch too large");
+    if (k == 0)
+        return PGPU_OK;
+    if (c->bvhs.empty())
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no bottom-level BVH is resident");
+    if (c->nStaged > 0)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    const int rc = traceLeafRecords(c, kind, tri_mode, records, k, results, stream);
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    return rc;
 }
 
 int pgpu_route_merge(pgpu_ctx* c, int kind, const float* results, const uint32_t* sent_slot, const uint32_t* sent_leaf, size_t k,

@@ -85,6 +85,84 @@ def _all_to_all_rows(rows: torch.Tensor, send_counts: torch.Tensor, staging_cpu:
     return (out.to(rows.device) if staging_cpu else out), recv_counts
 
 
+class HostStagedTransport:
+    """A pgpu_transport (include/pandora_hip.h) over torch.distributed with host staging: device buffers are copied to the
+    host, exchanged on the process group's backend (gloo), and copied back. For set-ups RCCL cannot serve -- several
+    ranks sharing one GPU, as in the two-process test -- and as the template for a caller-supplied transport (MPI, ...).
+    The product path on an 8-GPU node is pgpu_comm_init (RCCL)."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        self._C = C
+        self.group = group
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.world = dist.get_world_size(group)
+        self._keep = (capi.ALLGATHER_FN(self._allgather), capi.EXCHANGE_FN(self._exchange), capi.ALLREDUCE_FN(self._allreduce))
+
+    def struct(self):
+        return capi.Transport(None, *self._keep)
+
+    def _d2h(self, ptr, nbytes, stream):
+        host = torch.empty(max(nbytes, 1), dtype=torch.uint8)
+        if self.hip.hipStreamSynchronize(stream) != 0 or (nbytes and self.hip.hipMemcpy(host.data_ptr(), ptr, nbytes, 2) != 0):
+            raise RuntimeError("device -> host copy failed")
+        return host[:nbytes]
+
+    def _h2d(self, ptr, host):
+        if host.numel() and self.hip.hipMemcpy(ptr, host.data_ptr(), host.numel(), 1) != 0:
+            raise RuntimeError("host -> device copy failed")
+
+    def _allgather(self, user, send, recv, n, stream):
+        try:
+            mine = self._d2h(send, 4 * n, stream)
+            out = torch.empty(4 * n * self.world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group)
+            self._h2d(recv, out)
+            return 0
+        except Exception:
+            return 1
+
+    def _exchange(self, user, send, send_counts, recv, recv_counts, row_bytes, stream):
+        try:
+            sc = [int(send_counts[i]) * row_bytes for i in range(self.world)]
+            rc = [int(recv_counts[i]) * row_bytes for i in range(self.world)]
+            src = self._d2h(send, sum(sc), stream)
+            out = torch.empty(sum(rc), dtype=torch.uint8)
+            dist.all_to_all_single(out, src.contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+            self._h2d(recv, out)
+            return 0
+        except Exception:
+            return 1
+
+    def _allreduce(self, user, buf, n, stream):
+        try:
+            t = self._d2h(buf, 8 * n, stream).view(torch.int64).clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._h2d(buf, t.view(torch.uint8))
+            return 0
+        except Exception:
+            return 1
+
+
+def comm_init(ctx, device: torch.device, host_staged: bool = False):
+    """Gives `ctx` its communicator over the ranks of the default process group: RCCL (the unique id travels through a
+    broadcast on the process group) or, with host_staged, the HostStagedTransport above."""
+    rank, world = _world()
+    if host_staged:
+        ctx.comm_init_transport(rank, world, HostStagedTransport())
+        return
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).clone()
+    if world > 1:
+        on = uid.to(device) if dist.get_backend() == "nccl" else uid
+        dist.broadcast(on, src=0)
+        uid = on.cpu()
+    ctx.comm_init(rank, world, bytes(uid.numpy().tobytes()))
+
+
 class GpuEngine:
     """The product engine: pandora_hip through the C ABI, device tensors."""
 

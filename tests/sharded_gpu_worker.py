@@ -15,7 +15,8 @@ from pandora_amd import sharded  # noqa: E402
 
 
 def main():
-    out_dir, kind, device_records = sys.argv[1], int(sys.argv[2]), bool(int(sys.argv[3]))
+    out_dir, kind, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])  # mode 0 / 1: Python loop (torch / device records), 2: pgpu_trace_sharded
+    device_records = bool(mode)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -27,9 +28,21 @@ def main():
         ctx = pa.accel.Context(0)
         tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
         rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
-        eng = sharded.GpuEngine(ctx, dev, device_records=device_records)
-        st, info = sharded.trace_sharded(eng, torch.from_numpy(np.ascontiguousarray(rays)).to(dev), owner, kind)
-        cnt = ctx.counters()
+        d_rays = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)
+        if mode == 2:
+            # the whole loop inside the library; the collectives go through host memory + gloo (two ranks share one GPU, which RCCL refuses)
+            sharded.comm_init(ctx, dev, host_staged=True)
+            ctx.comm_selftest()
+            ctx.set_leaf_owners(owner)
+            st, cnt = ctx.trace_sharded(d_rays, kind=kind)
+            info = {"routed": cnt["records_routed"], "rounds": cnt["rounds"], "leaf_visits": cnt["leaf_visits"]}
+            film = torch.full((5, 3), rank + 1, dtype=torch.int64, device=dev)
+            ctx.film_allreduce(film)
+            assert bool((film == 3).all()), "pgpu_film_allreduce over the host-staged transport"
+        else:
+            eng = sharded.GpuEngine(ctx, dev, device_records=device_records)
+            st, info = sharded.trace_sharded(eng, d_rays, owner, kind)
+            cnt = ctx.counters()
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), routed=info["routed"], rounds=info["rounds"], leaf_visits=info["leaf_visits"],
                  svdag_tests=cnt["svdag_tests"], svdag_culled=cnt["svdag_culled"],
                  **{k: v.cpu().numpy() for k, v in st.items() if k not in ("node", "stack")})

@@ -76,7 +76,42 @@ def test_trace_rejects_non_resident_leaves():
     ctx.close()
 
 
-@pytest.mark.parametrize("device_records", [1, 0], ids=["device_records", "torch_records"])
+@pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
+def test_c_abi_loop_one_rank_over_rccl(scene, kind):
+    """pgpu_trace_sharded with a real RCCL communicator of one rank (the only size one GPU allows): the library loads
+    librccl, creates the communicator, and the loop -- every batching point local -- equals pgpu_trace bit for bit."""
+    import torch
+    ctx, mesh, tl = scene
+    rays = _rays(mesh)
+    want, wcnt = ctx.trace(rays, kind=kind)
+    ctx.comm_init(0, 1, pa.accel.Context.comm_unique_id())
+    try:
+        ctx.comm_selftest()  # ncclAllGather, ncclAllReduce and a grouped ncclSend / ncclRecv (to itself) run on the GPU
+        ctx.set_leaf_owners(np.zeros(tl.n_leaves, np.uint32))
+        got, cnt = ctx.trace_sharded(torch.from_numpy(rays).cuda(), kind=kind)
+        for k in (("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")):
+            assert np.array_equal(_bits(got[k].cpu().numpy()), _bits(want[k])), k
+        for k in ("rounds", "leaf_visits", "svdag_tests", "svdag_culled"):
+            assert cnt[k] == wcnt[k], k
+        assert cnt["records_routed"] == 0 and cnt["exchange_bytes"] == 0
+        # the film all-reduce of one rank leaves the film alone; a 1-rank ncclAllReduce still has to run: do one directly
+        film = torch.arange(30, dtype=torch.int64, device="cuda").reshape(10, 3).contiguous()
+        ctx.film_allreduce(film)
+        assert bool((film.cpu() == torch.arange(30).reshape(10, 3)).all())
+    finally:
+        ctx.comm_destroy()
+
+
+def test_set_leaf_owners_checks_residency(scene):
+    ctx, mesh, tl = scene
+    ctx.comm_destroy()
+    with pytest.raises(pa.capi.PandoraError):
+        ctx.set_leaf_owners(np.ones(tl.n_leaves, np.uint32))  # rank 1 of a 1-rank world
+    with pytest.raises(pa.capi.PandoraError):
+        ctx.set_leaf_owners(np.zeros(tl.n_leaves + 1, np.uint32))
+
+
+@pytest.mark.parametrize("device_records", [2, 1, 0], ids=["c_abi_loop", "device_records", "torch_records"])
 @pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
 def test_two_processes_sharded_leaves(scene, kind, device_records):
     ctx, mesh, tl = scene
