@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Mrays/s of incoherent diffuse-bounce rays (BASELINE.json `metric`).
 
-A step = one closest-hit pass of the single-level WiVe BVH8 kernel over one batch of R-diffuse rays
-(one cosine-weighted bounce per primary hit, order shuffled) of the Sponza-class synthetic atrium
-(BASELINE.json configs[1]; the real asset is not available offline). Rays and the scene
-are resident in HBM when the timed region starts. With --gpus N every rank holds the whole (in-core)
-scene and traces its own batch: the path shards by rays, no collective in the data path (weak scaling).
+Default (`--config single`, the configuration the metric is quoted on): a step = one closest-hit pass of the
+single-level WiVe BVH8 kernel over one batch of R-diffuse rays (one cosine-weighted bounce per primary hit, order
+shuffled) of the Sponza-class synthetic atrium (BASELINE.json configs[1]; the real asset is not available offline,
+SURVEY.md 8d). `--config two-level`: the same ray set through the two-level path (PauseableBVH4 + 64^3 SVDAGs + per-point
+BVH8) of a San-Miguel-class synthetic city (configs[2]). Rays and scene are resident in HBM when the timed region starts.
 
-Prints ONE JSON line (rank 0). `roofline` prices the traversal kernel against HBM with the algorithmic
-bytes of SURVEY.md 8d (52 B/ray + the scene read once per launch); `cpu_baseline` times the CPU oracle
-(a port of the reference's traversal, oracle/) on a bounded sample of the same rays on the host cores.
+`--gpus N`: one process per GPU. Started by the driver under torch.distributed.run the ranks are already there; started
+plainly (`python bench.py --gpus N`) this process starts the N ranks itself, before anything touches a GPU. Every rank
+holds the whole in-core scene and traces its own batch (the path shards by rays: weak scaling, no collective in the data
+path) -- and, for N > 1, the line also carries a `sharded` record: the two-level loop with the batching points of the city
+sharded over the ranks' HBM and ray records routed by RCCL all-to-all (pgpu_trace_sharded, configs[3]).
+
+Prints ONE JSON line (rank 0). `roofline` prices the traversal against HBM with the algorithmic bytes of SURVEY.md 8d;
+`cpu_baseline` times the CPU port of the reference's traversal (oracle/) on a bounded sample of the same rays on the
+host cores and checks the GPU result against it bit for bit.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,50 +34,86 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MISS = np.uint32(0xFFFFFFFF)
 
 
-def main() -> None:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=["single", "two-level"], default="single", help="configs[1] (default, the headline) or configs[2]")
     ap.add_argument("--side", type=int, default=4096, help="primary-ray image side; batch ~ side^2 diffuse rays")
     ap.add_argument("--tris", type=int, default=262144)
     ap.add_argument("--kind", choices=["closest", "any"], default="closest")
     ap.add_argument("--tri", choices=["moller-trumbore", "watertight"], default="moller-trumbore",
                     help="leaf test: the branch the reference compiles (triangle_intersect.cpp:425-462) or its watertight variant (:340-423)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 24, help="rays of the batch the CPU oracle traces (and the GPU result is compared on): the whole batch by default, ~20 s of CPU work")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="rays of the batch the CPU port traces (and the GPU result is compared on); 0 = automatic: the whole batch for the single-level config (~20 s of CPU work), 2^21 rays for two-level")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--city-blocks", type=int, default=24, help="two-level / sharded scene: city blocks per side (24 -> 11.4 M triangles)")
+    ap.add_argument("--sharded-side", type=int, default=2048, help="N > 1: primary image side per rank of the sharded record")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded record")
+    ap.add_argument("--force-sharded", action="store_true", help="N = 1: run the sharded record too (one rank owns every batching point; rehearsal of the N > 1 path)")
+    ap.add_argument("--dry", action="store_true", help="no GPU: the ranks only meet (gloo) and reduce made-up figures; checks the launch path")
+    return ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
 
-    import pandora_amd as pa
+# ---------------------------------------------------------------------------------------------- starting the ranks
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N children (one per GPU) with the torch.distributed
+    environment and wait for them. This process never touches a GPU; rank 0's stdout (the JSON line) is inherited."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PANDORA_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
 
-    # ---- scene (replicated per rank) and ray sets
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def cpu_trace_single(orc, rays, any_hit, tri_mode, threads):
+    """The CPU port on `threads` host threads: the AVX2 form (the loops restated on the reference's own simd headers,
+    oracle/_ref, built in the container) when it is there, else the scalar C form. Same results either way."""
+    import oracle_binding as ob
+    if not ob.have_ref():
+        return orc.trace(rays, any_hit=any_hit, tri_mode=tri_mode, threads=threads), "scalar C (oracle/pandora_oracle.c)"
+    from concurrent.futures import ThreadPoolExecutor
+    n = rays.shape[1]
+    cuts = np.linspace(0, n, 4 * threads + 1).astype(np.int64)
+    parts = [np.ascontiguousarray(rays[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    with ThreadPoolExecutor(threads) as pool:  # (ctypes releases the GIL)
+        res = list(pool.map(lambda r: orc.trace(r, any_hit=any_hit, tri_mode=tri_mode, use_ref=True), parts))
+    out = {k: np.concatenate([r[k] for r in res]) for k in res[0] if k != "counters"}
+    return out, "AVX2 (loops restated on the reference's simd8/simd4 headers, oracle/_ref)"
+
+
+def avx2_ratio():
+    try:
+        with open(os.path.join(ROOT, "profiles", "r2_cpu_baseline_ratio.json")) as fh:
+            return json.load(fh)["avx2_over_scalar"]
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------- the configurations
+def run_single(args, pa, torch, ctx, dev, rank):
+    """configs[1]: in-core single-level BVH8. Returns (step fn, n rays, finish fn -> (config, roofline, cpu_baseline))."""
     mesh = pa.scenes.g_atrium(args.tris)
     hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
-    ctx = pa.accel.Context(dev.index)
     bvh = ctx.upload_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
     stream = torch.cuda.current_stream().cuda_stream
-
     prim = pa.scenes.primary_rays((3, 3, 9), (28, 5, 9), (0, 1, 0), 70, args.side, args.side, seed=891379 + 7919 * rank)
     d_prim = torch.from_numpy(prim).to(dev)
     first = ctx.trace_bvh8(bvh, d_prim, stream=stream)
     torch.cuda.synchronize()
     t_hit = first["t"].cpu().numpy()
     obj = first["obj"].cpu().numpy().view(np.uint32)
-    prim_id = np.where(obj == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), hb.prim_ids[np.minimum(obj, hb.prim_ids.size - 1)])
+    prim_id = np.where(obj == MISS, MISS, hb.prim_ids[np.minimum(obj, hb.prim_ids.size - 1)])
     rays = pa.scenes.diffuse_bounce_rays(mesh, prim, t_hit, prim_id, seed=891379 + 7919 * rank)
     del d_prim, first
     n = int(rays.shape[1])
@@ -80,6 +124,222 @@ def main() -> None:
 
     def step():
         ctx.trace_bvh8(bvh, d_rays, kind=kind, tri_mode=tri_mode, out=out, stream=stream)
+
+    def finish(k_ms, world):
+        scene_bytes = hb.scene_bytes(mesh.n_verts)
+        per_ray = 52 if args.kind == "closest" else 36
+        alg_bytes = per_ray * n + scene_bytes
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        hit_frac = float((out["obj"].cpu().numpy().view(np.uint32) != MISS).mean()) if args.kind == "closest" else float(out["hit"].cpu().numpy().mean())
+        cpu = None
+        if not args.no_cpu:
+            import oracle_binding as ob
+            threads = max(1, min(16, os.cpu_count() or 1))
+            sample = min(n, args.cpu_sample or n)
+            orc = ob.OracleBvh8.from_host(hb, mesh)
+            sub = np.ascontiguousarray(rays[:, :sample])
+            c0 = time.perf_counter()
+            want, form = cpu_trace_single(orc, sub, args.kind == "any", tri_mode, threads)
+            c1 = time.perf_counter()
+            if args.kind == "closest":
+                same = all(np.array_equal(out[k][:sample].cpu().numpy().view(np.uint32), want[k].view(np.uint32)) for k in ("t", "obj", "u", "v"))
+            else:
+                same = bool(np.array_equal(out["hit"][:sample].cpu().numpy().view(np.uint32), want["hit"]))
+            # visit counters (secondary figure) from the scalar form on a small slice: bytes a ray pulls through the caches
+            cnt = orc.trace(np.ascontiguousarray(sub[:, :min(sample, 1 << 18)]), any_hit=(args.kind == "any"), tri_mode=tri_mode, threads=threads)["counters"]
+            m = min(sample, 1 << 18)
+            vpr = {k: cnt[k] / m for k in ("inner_visits", "leaf_pops", "tri_tests")}
+            cpu = {"value": sample / (c1 - c0) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": f"first {sample} rays of the same R-diffuse batch; WiVeBVH8::intersect restated, {form}, {threads} threads",
+                   "avx2_over_scalar_in_container": avx2_ratio(), "gpu_matches_bit_exact": bool(same), "visits_per_ray": vpr,
+                   "traversal_model_bytes_per_ray": 256.0 * vpr["inner_visits"] + 4.0 * vpr["tri_tests"] + 48.0 * vpr["tri_tests"]}
+        # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command
+        # (tools/pmc_passes.sh), which cannot run inside the timed process; the committed summary is quoted.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if args.kind == "closest" and args.tri == "moller-trumbore" and os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("rays_per_launch") == n:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/pmc_traffic.json (" + tj["how"] + ")"
+        config = {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, args.kind),
+                  "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
+                  "triangle_test": args.tri, "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "scene_bytes": scene_bytes}
+        if cpu is not None:
+            roofline["traversal_model_GBps"] = cpu["traversal_model_bytes_per_ray"] * n / (k_ms * 1e-3) / 1e9
+        return config, roofline, cpu
+
+    return step, n, finish
+
+
+def city_scene(pa, blocks, build_group=None):
+    mesh = pa.scenes.g_city(blocks, 18750)
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 65536, svdag_res=64, build_group=build_group)
+    return mesh, tl
+
+
+def city_camera(pa, blocks, side, seed):
+    size = 20.0 * blocks
+    return pa.scenes.primary_rays((0.1 * size, 14.0, 0.1 * size), (0.6 * size, 0.0, 0.6 * size), (0, 1, 0), 60, side, side, seed=seed)
+
+
+def run_two_level(args, pa, torch, ctx, dev, rank):
+    """configs[2]: PauseableBVH4 + 64^3 SVDAGs + per-point BVH8 on one GPU (the whole round loop is the step)."""
+    mesh, tl = city_scene(pa, args.city_blocks)
+    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+    stream = torch.cuda.current_stream().cuda_stream
+    prim = city_camera(pa, args.city_blocks, args.side, 891379 + 7919 * rank)
+    first, _ = ctx.trace(torch.from_numpy(prim).to(dev), stream=stream)
+    prim_id = tl.prim_ids_of(first["leaf"].cpu().numpy(), first["obj"].cpu().numpy())
+    rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379 + 7919 * rank)
+    del first
+    n = int(rays.shape[1])
+    d_rays = torch.from_numpy(rays).to(dev)
+    kind = pa.capi.CLOSEST if args.kind == "closest" else pa.capi.ANY
+    tri_mode = pa.capi.TRI_MT if args.tri == "moller-trumbore" else pa.capi.TRI_WATERTIGHT
+    out, cnt = ctx.trace(d_rays, kind=kind, tri_mode=tri_mode, stream=stream)
+    state = {"cnt": cnt}
+
+    def step():
+        _, state["cnt"] = ctx.trace(d_rays, kind=kind, tri_mode=tri_mode, out=out, stream=stream)
+
+    def finish(k_ms, world):
+        cnt = state["cnt"]
+        scene_bytes = tl.device_bytes(mesh.n_verts)
+        per_ray = 52 if args.kind == "closest" else 36
+        # SURVEY.md 8d: per (ray, batching-point visit) a park + a resume record of 44 bytes each (ray 32 + token 12)
+        alg_bytes = per_ray * n + 88 * cnt["leaf_visits"] + scene_bytes
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        cpu = None
+        if not args.no_cpu:
+            import oracle_binding as ob
+            threads = max(1, min(16, os.cpu_count() or 1))
+            sample = min(n, args.cpu_sample or (1 << 21))
+            sub = np.ascontiguousarray(rays[:, :sample])
+            scene = ob.scene_from_two_level(tl, mesh)
+            c0 = time.perf_counter()
+            want = scene.trace(sub, any_hit=(args.kind == "any"), tri_mode=tri_mode, lanes=3, threads=threads)
+            c1 = time.perf_counter()
+            keys = ("hit", "visits") if args.kind == "any" else ("t", "obj", "leaf", "u", "v", "visits")
+            same = all(np.array_equal(out[k][:sample].cpu().numpy().view(np.uint32), want[k].view(np.uint32)) for k in keys)
+            cpu = {"value": sample / (c1 - c0) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": f"first {sample} rays of the same R-diffuse batch; PauseableBVH4::intersectT + SparseVoxelDAG::intersectScalar + WiVeBVH8::intersect restated in scalar C (oracle/pandora_oracle.c), {threads} pthreads",
+                   "gpu_matches_bit_exact": bool(same)}
+        config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with 64^3 SVDAG early-out + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.kind),
+                  "rays_per_gpu": n, "triangles": mesh.n_tris, "batching_points": tl.n_leaves, "triangle_test": args.tri,
+                  "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
+                  "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "the round loop (topTraverseKernel + leafScan / binByLeaf + bvh8TraceKernel, all rounds), device time between the loop's first and last event",
+                    "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "bytes_per_leaf_visit": 88, "scene_bytes": scene_bytes}
+        return config, roofline, cpu
+
+    return step, n, finish
+
+
+def run_sharded(args, pa, torch, dist, dev, rank, world):
+    """configs[3]: batching points sharded over the ranks' HBM, records routed by RCCL (pgpu_trace_sharded). Every rank
+    builds only the BVHs of its own batching points. Returns the `sharded` record (rank 0) or None."""
+    from pandora_amd import sharded
+    owner_by_group = {}
+
+    def mine(sizes):
+        owner_by_group["o"] = sharded.assign_leaves(sizes, world)  # balanced by triangle count; deterministic on every rank
+        return owner_by_group["o"] == rank
+
+    t0 = time.perf_counter()
+    mesh, tl = city_scene(pa, args.city_blocks, build_group=mine)
+    owner = owner_by_group["o"][np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
+    ctx = pa.accel.Context(dev.index)
+    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
+    sharded.comm_init(ctx, dev)  # RCCL communicator of the library's own; the unique id travels through torch.distributed
+    ctx.comm_selftest()
+    ctx.set_leaf_owners(owner)
+    build_s = time.perf_counter() - t0
+    prim = city_camera(pa, args.city_blocks, args.sharded_side, 891379 + 7919 * rank)
+    first, _ = ctx.trace_sharded(torch.from_numpy(prim).to(dev))
+    prim_id = tl.prim_ids_of(first["leaf"].cpu().numpy(), first["obj"].cpu().numpy())
+    rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379 + 7919 * rank)
+    d_rays = torch.from_numpy(rays).to(dev)
+    n = int(rays.shape[1])
+    out, cnt = ctx.trace_sharded(d_rays)  # warm-up, allocates the result arrays and the record buffers
+    steps = max(1, min(args.steps, 10))
+    multi = world > 1
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, cnt = ctx.trace_sharded(d_rays, out=out)
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mx = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    sums = torch.tensor([n, cnt["leaf_visits"], cnt["records_routed"], cnt["exchange_bytes"], 1,
+                         sum(256 * b.n_nodes + 48 * b.leaf_idx.size for b in tl.bvhs if b is not None)], dtype=torch.float64, device=dev)
+    if multi:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    rec = None
+    if rank == 0:
+        total_rays, visits, routed, xbytes, ranks, resident = (float(x) for x in sums.tolist())
+        el = float(mx.item())
+        rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, 64^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (mesh.n_tris, tl.n_leaves, world),
+               "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
+               "comm_selftest": "ok", "value": total_rays * steps / el / 1e6, "unit": "Mrays/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
+               "rays_per_gpu": n, "rounds": cnt["rounds"], "leaf_visits_per_ray": visits / total_rays, "records_routed_per_step": routed,
+               "records_routed_fraction": routed / max(1.0, visits), "exchange_bytes_per_step_all_ranks": xbytes,
+               "bytes_per_all_to_all_per_rank": xbytes / max(1.0, ranks * 2 * max(1, cnt["rounds"])),
+               "resident_bvh_bytes_total": resident, "scene_build_s_rank0": build_s}
+    ctx.close()
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------- main
+def main() -> int:
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if args.dry:
+        # launch-path check without a GPU: the ranks meet on gloo, reduce made-up figures the way the real run does
+        from pandora_amd.sharded import reduce_job
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.zeros(max(world, 1), dtype=torch.int64)
+        seen[rank] = 1
+        if world > 1:
+            dist.all_reduce(seen)
+        elapsed, total = reduce_job(0.001 * (rank + 1), 1000, None)
+        if rank == 0:
+            print(json.dumps({"metric": "Mrays/s incoherent diffuse rays", "value": total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "dry": True,
+                              "ranks_seen": [int(i) for i in torch.nonzero(seen).flatten().tolist()], "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    import pandora_amd as pa
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    ctx = pa.accel.Context(dev.index)
+    step, n, finish = (run_single if args.config == "single" else run_two_level)(args, pa, torch, ctx, dev, rank)
 
     for _ in range(args.warmup):
         step()
@@ -93,7 +353,7 @@ def main() -> None:
         step()
         # per-launch kernel time from HIP events recorded by the library on this same stream; reading
         # them needs the step to have finished, which also keeps one batch in flight at a time
-        ctx.sync(stream)
+        ctx.sync(torch.cuda.current_stream().cuda_stream)
         kernel_ms.append(ctx.last_kernel_ms())
     torch.cuda.synchronize()
     if world > 1:
@@ -103,65 +363,27 @@ def main() -> None:
     from pandora_amd.sharded import reduce_job
     elapsed, total_rays = reduce_job(elapsed, n, dev)  # max over ranks, rays summed over ranks
 
+    line = None
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = total_rays * args.steps / elapsed / 1e6
         k_ms = float(np.mean(kernel_ms))
-        scene_bytes = hb.scene_bytes(mesh.n_verts)
-        per_ray = 52 if args.kind == "closest" else 36
-        alg_bytes = per_ray * n + scene_bytes
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        hit_frac = float((out["obj"].cpu().numpy().view(np.uint32) != 0xFFFFFFFF).mean()) if args.kind == "closest" else float(out["hit"].cpu().numpy().mean())
-        cpu = None
-        if not args.no_cpu:
-            import oracle_binding as ob
-            threads = max(1, min(16, os.cpu_count() or 1))
-            sample = min(n, args.cpu_sample)
-            orc = ob.OracleBvh8.from_host(hb, mesh)
-            sub = np.ascontiguousarray(rays[:, :sample])
-            c0 = time.perf_counter()
-            want = orc.trace(sub, any_hit=(args.kind == "any"), tri_mode=tri_mode, threads=threads)
-            c1 = time.perf_counter()
-            if args.kind == "closest":
-                same = all(np.array_equal(out[k][:sample].cpu().numpy().view(np.uint32), want[k].view(np.uint32)) for k in ("t", "obj", "u", "v"))
-            else:
-                same = bool(np.array_equal(out["hit"][:sample].cpu().numpy().view(np.uint32), want["hit"]))
-            cpu = {"value": sample / (c1 - c0) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-                   "sample": f"first {sample} rays of the same R-diffuse batch, oracle/pandora_oracle.c (scalar restatement of WiVeBVH8::intersect), {threads} pthreads",
-                   "gpu_matches_bit_exact": bool(same),
-                   "visits_per_ray": {k: want["counters"][k] / sample for k in ("inner_visits", "leaf_pops", "tri_tests")}}
-            # SURVEY.md 8d, secondary figure: bytes a ray pulls through the caches (256 B per inner visit, 4 B per leaf index,
-            # 48 B per triangle record), from the oracle's visit counters -- what L2 / Infinity Cache must serve
-            vpr = cpu["visits_per_ray"]
-            cpu["traversal_model_bytes_per_ray"] = 256.0 * vpr["inner_visits"] + 4.0 * vpr["tri_tests"] + 48.0 * vpr["tri_tests"]
-        # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command
-        # (tools/pmc_passes.sh), which cannot run inside the timed process; the committed summary is quoted.
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.kind == "closest" and args.tri == "moller-trumbore" and os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            if tj.get("rays_per_launch") == n:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/pmc_traffic.json (" + tj["how"] + ")"
-        line = {
-            "metric": "Mrays/s incoherent diffuse rays", "value": value, "unit": "Mrays/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, args.kind),
-                       "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
-                       "triangle_test": args.tri, "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "scene_bytes": scene_bytes},
-            "cpu_baseline": cpu,
-        }
-        if cpu is not None:
-            line["roofline"]["traversal_model_GBps"] = cpu["traversal_model_bytes_per_ray"] * n / (k_ms * 1e-3) / 1e9
-        print(json.dumps(line), flush=True)
+        config, roofline, cpu = finish(k_ms, world)
+        line = {"metric": "Mrays/s incoherent diffuse rays", "value": total_rays * args.steps / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "cpu_baseline": cpu}
     ctx.close()
+    if (world > 1 or args.force_sharded) and not args.no_sharded:
+        try:
+            rec = run_sharded(args, pa, torch, dist, dev, rank, world)
+        except Exception as e:  # the headline figure stands on its own: report the failure instead of losing the line
+            rec = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            line["sharded"] = rec
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

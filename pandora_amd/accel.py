@@ -509,6 +509,22 @@ class TwoLevelScene:
     def n_leaves(self) -> int:
         return len(self.groups)
 
+    def prim_ids_of(self, leaf: np.ndarray, obj: np.ndarray) -> np.ndarray:
+        """Mesh triangle id of every hit record (leaf slot, leaf-object index); MISS stays MISS."""
+        leaf, obj = np.asarray(leaf).view(np.uint32), np.asarray(obj).view(np.uint32)
+        out = np.full(obj.shape, capi.MISS, np.uint32)
+        hit = obj != np.uint32(capi.MISS)
+        for l in np.unique(leaf[hit]):
+            m = hit & (leaf == l)
+            out[m] = self.groups[int(self.top.leaf_order[int(l)])][obj[m]]  # (leaf object j of a point = its j-th triangle)
+        return out
+
+    def device_bytes(self, n_verts: int = 0) -> int:
+        """Bytes of the structure as the traversal reads it: 256-byte nodes, leaf indices, triangles, top level, SVDAG words."""
+        b = sum(256 * h.n_nodes + 4 * h.leaf_idx.size + 12 * h.prim_ids.size for h in self.bvhs if h is not None)
+        b += 112 * int(self.top.nodes.shape[0]) + 12 * n_verts
+        return b + (4 * int(self.dags.words.size) if self.dags is not None else 0)
+
     def upload(self, ctx: "Context", mesh_id: int, resident=None, streamed: bool = False):
         """Uploads BVHs, SVDAGs and the top level. Returns bvh ids in final leaf-slot order.
 
@@ -518,7 +534,7 @@ class TwoLevelScene:
         slot_of = np.empty(self.n_leaves, np.int64)
         slot_of[np.asarray(self.top.leaf_order, np.int64)] = np.arange(self.n_leaves)
         put = ctx.stage_bvh8 if streamed else ctx.upload_bvh8  # streamed: leaves live in pinned host memory (config 5)
-        ids = [put(b, mesh_id) if (resident is None or bool(resident[slot_of[i]])) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
+        ids = [put(b, mesh_id) if (b is not None and (resident is None or bool(resident[slot_of[i]]))) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
         if self.dags is not None:
             ctx.upload_svdags(self.dags)
         leaves = np.empty((self.n_leaves, 2), np.uint32)
@@ -529,7 +545,9 @@ class TwoLevelScene:
         return leaves[:, 0].copy()
 
 
-def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4) -> TwoLevelScene:
+def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4, build_group=None) -> TwoLevelScene:
+    """build_group: optional callable (group sizes: int array) -> bool array; only those batching points get a bottom-level
+    BVH8 here (the others stay None: they live on another rank). The cut, the top level and the SVDAGs are always whole."""
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
     group_of, ng = partition_prims(pos, idx, prims_per_batching_point)
@@ -539,12 +557,14 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     groups = [np.ascontiguousarray(order[starts[g]:starts[g + 1]]) for g in range(ng)]
     # the per-group builds are independent C calls (ctypes releases the GIL): run them on a few threads
     workers = max(1, min(16, os.cpu_count() or 1, len(groups)))
+    want = np.ones(ng, bool) if build_group is None else np.asarray(build_group(counts), bool)
+    build = lambda gi: build_bvh8(pos, idx, groups[gi], max_leaf) if want[gi] else None
     if workers > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(workers) as pool:
-            bvhs = list(pool.map(lambda g: build_bvh8(pos, idx, g, max_leaf), groups))
+            bvhs = list(pool.map(build, range(ng)))
     else:
-        bvhs = [build_bvh8(pos, idx, g, max_leaf) for g in groups]
+        bvhs = [build(gi) for gi in range(ng)]
     bounds = np.empty((ng, 6), np.float32)
     for g, prims in enumerate(groups):
         v = pos[idx[prims].ravel()]
