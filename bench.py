@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=0, help="rays of the batch the CPU port traces (and the GPU result is compared on); 0 = automatic: the whole batch for the single-level config (~20 s of CPU work), 2^21 rays for two-level")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--city-blocks", type=int, default=24, help="two-level / sharded scene: city blocks per side (24 -> 11.4 M triangles)")
+    ap.add_argument("--svdag", type=int, default=64, help="two-level / sharded scene: SVDAG resolution (0 = no proxy geometry, svdagRes 0 in the reference)")
     ap.add_argument("--sharded-side", type=int, default=2048, help="N > 1: primary image side per rank of the sharded record")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded record")
     ap.add_argument("--force-sharded", action="store_true", help="N = 1: run the sharded record too (one rank owns every batching point; rehearsal of the N > 1 path)")
@@ -175,9 +176,9 @@ def run_single(args, pa, torch, ctx, dev, rank):
     return step, n, finish
 
 
-def city_scene(pa, blocks, build_group=None):
+def city_scene(pa, blocks, build_group=None, svdag=64):
     mesh = pa.scenes.g_city(blocks, 18750)
-    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 65536, svdag_res=64, build_group=build_group)
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 65536, svdag_res=svdag, build_group=build_group)
     return mesh, tl
 
 
@@ -188,7 +189,7 @@ def city_camera(pa, blocks, side, seed):
 
 def run_two_level(args, pa, torch, ctx, dev, rank):
     """configs[2]: PauseableBVH4 + 64^3 SVDAGs + per-point BVH8 on one GPU (the whole round loop is the step)."""
-    mesh, tl = city_scene(pa, args.city_blocks)
+    mesh, tl = city_scene(pa, args.city_blocks, svdag=args.svdag)
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
     stream = torch.cuda.current_stream().cuda_stream
     prim = city_camera(pa, args.city_blocks, args.side, 891379 + 7919 * rank)
@@ -228,7 +229,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
             cpu = {"value": sample / (c1 - c0) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                    "sample": f"first {sample} rays of the same R-diffuse batch; PauseableBVH4::intersectT + SparseVoxelDAG::intersectScalar + WiVeBVH8::intersect restated in scalar C (oracle/pandora_oracle.c), {threads} pthreads",
                    "gpu_matches_bit_exact": bool(same)}
-        config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with 64^3 SVDAG early-out + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.kind),
+        config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with %d^3 SVDAG early-out + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.svdag, args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "batching_points": tl.n_leaves, "triangle_test": args.tri,
                   "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
@@ -251,7 +252,7 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
         return owner_by_group["o"] == rank
 
     t0 = time.perf_counter()
-    mesh, tl = city_scene(pa, args.city_blocks, build_group=mine)
+    mesh, tl = city_scene(pa, args.city_blocks, build_group=mine, svdag=args.svdag)
     owner = owner_by_group["o"][np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
     ctx = pa.accel.Context(dev.index)
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
@@ -290,7 +291,7 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
     if rank == 0:
         total_rays, visits, routed, xbytes, ranks, resident = (float(x) for x in sums.tolist())
         el = float(mx.item())
-        rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, 64^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (mesh.n_tris, tl.n_leaves, world),
+        rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, %d^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (mesh.n_tris, tl.n_leaves, args.svdag, world),
                "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
                "comm_selftest": "ok", "value": total_rays * steps / el / 1e6, "unit": "Mrays/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
                "rays_per_gpu": n, "rounds": cnt["rounds"], "leaf_visits_per_ray": visits / total_rays, "records_routed_per_step": routed,
@@ -306,6 +307,15 @@ def main() -> int:
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args)
+
+    # Libraries below us write to stdout (RCCL prints a version banner there): the one JSON line must be the only thing on
+    # it, so file descriptor 1 points at stderr until the line is written.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
     import torch
     import torch.distributed as dist
@@ -325,8 +335,8 @@ def main() -> int:
             dist.all_reduce(seen)
         elapsed, total = reduce_job(0.001 * (rank + 1), 1000, None)
         if rank == 0:
-            print(json.dumps({"metric": "Mrays/s incoherent diffuse rays", "value": total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "dry": True,
-                              "ranks_seen": [int(i) for i in torch.nonzero(seen).flatten().tolist()], "steps": args.steps, "warmup": args.warmup}), flush=True)
+            emit({"metric": "Mrays/s incoherent diffuse rays", "value": total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "dry": True,
+                  "ranks_seen": [int(i) for i in torch.nonzero(seen).flatten().tolist()], "steps": args.steps, "warmup": args.warmup})
         if world > 1:
             dist.destroy_process_group()
         return 0
@@ -379,7 +389,7 @@ def main() -> int:
         if rank == 0:
             line["sharded"] = rec
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
     return 0
