@@ -60,6 +60,10 @@ const uint32_t* pgpu_host_bvh8_leaf_indices(const pgpu_host_bvh8*, size_t* n_ind
 uint32_t pgpu_host_bvh8_root(const pgpu_host_bvh8*);
 int pgpu_host_bvh8_depth(const pgpu_host_bvh8*); /* nested inner nodes on the longest path */
 void pgpu_host_bvh8_free(pgpu_host_bvh8*);
+/* BVH8 over arbitrary leaf objects given by their bounds (n_objects x {min xyz, max xyz}); leaf object j = box j. An object
+ * with alone[j] != 0 gets a leaf of its own (instances; alone may be NULL). What LRUBVHSceneCache::createBVH builds over
+ * the mix of instanced sub-scenes and triangles of a sub-scene (offline_bvh_cache.cpp:273-309). */
+int pgpu_build_bvh8_boxes(const float* bounds6, size_t n_objects, const uint8_t* alone, uint32_t max_leaf, pgpu_host_bvh8** out);
 
 /* BVH4 over batching-point bounds (n_leaves x {min xyz, max xyz}); leaf_order[k] = input leaf stored
  * at final leaf slot k (the reference moves leaves into m_leafs in this order, :461-467). */
@@ -73,6 +77,14 @@ void pgpu_host_bvh4_free(pgpu_host_bvh4*);
 /* Groups triangles into batching points of <= max_prims primitives (primitivesPerBatchingPoint). */
 int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
     size_t max_prims, uint32_t* group_of_prim, uint32_t* n_groups);
+
+/* The same cut at the level the reference makes it -- over scene objects (shapes, instanced sub-scenes) given by their bounds
+ * and primitive counts: detail::createSubScenes, batching.cpp:38-265 (BVH2 over the objects, cut where a subtree holds
+ * <= primitivesPerBatchingPoint primitives, :161-224). weights may be NULL (1 each). An object heavier than max_weight ends
+ * up alone: split such shapes first, as the reference does with splitLargeSceneObjects at primitivesPerBatchingPoint / 8
+ * (batching.cpp:358-422, offline_batching_acceleration_structure.cpp:57) -- pgpu_partition_prims over the shape's triangles. */
+int pgpu_partition_objects(const float* bounds6, const uint64_t* weights, size_t n_objects, uint64_t max_weight, uint32_t* group_of_object,
+    uint32_t* n_groups);
 
 /* Voxelises each group of triangles into a resolution^3 grid over the group's bounds
  * (TriangleShape::voxelize, triangle_intersect.cpp:224-329), builds one SVO per group
@@ -122,11 +134,33 @@ int pgpu_upload_mesh(pgpu_ctx*, const float* positions, size_t n_vertices, const
  * plus its leaf-object table: leaf object j is primitive objs[j].prim of mesh objs[j].mesh
  * (OfflineBVHLeaf::Primitive, offline_bvh_cache.h:18-39). */
 typedef struct {
-    uint32_t mesh;
+    uint32_t mesh; /* PGPU_INSTANCE: the leaf object is instance number `prim` of the table given with it */
     uint32_t prim;
 } pgpu_leafobj;
 int pgpu_upload_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
+
+/* Instanced leaves: OfflineBVHLeaf::Instance (offline_bvh_cache.h:18-39, .cpp:21-29,54-61,74-77; made by
+ * LRUBVHSceneCache::createBVH, :278-297). A leaf object may be a whole other BVH (an already uploaded bvh_id) under a
+ * transform. world_to_local = rows 0..2 of Transform::m_inverseMatrix = glm::inverse(localToWorld), row-major 3x4.
+ * Semantics: the ray is taken to the instance's space with Transform::transformToLocal (graphics_core/transform.cpp:40-45:
+ * origin = inverse * (o, 1), direction = inverse * (d, 0), tnear / tfar unchanged) and the instance's BVH is traversed with
+ * it; a hit shortens the world ray's tfar to the same t. The reference's own offline path forgets that transform (it hands the
+ * nested traversal the world-space ray) -- its Embree-backed structures do it as described
+ * (batching_acceleration_structure.h:411-422), and that is what is implemented: REF-UNPINNED.
+ * Limits: one level (the instanced BVH holds no instances itself), an instance sits alone in its leaf (pgpu_build_bvh8_boxes
+ * with the `alone` flag builds such trees), instanced BVHs must be resident (pgpu_upload_bvh8; the BVH that holds the
+ * instances may be staged), and the leaf-sharded entry points do not route instance hits yet (they refuse such contexts).
+ * Hit records: obj = leaf object inside the INSTANCED BVH, pgpu_hits.inst = leaf object (the instance) inside the traced BVH. */
+#define PGPU_INSTANCE 0xFFFFFFFFu
+typedef struct {
+    uint32_t bvh_id;
+    float world_to_local[12];
+} pgpu_instance;
+int pgpu_upload_bvh8_instanced(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, uint32_t* bvh_id);
+int pgpu_stage_bvh8_instanced(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, uint32_t* bvh_id);
 
 /* Leaves streamed from host memory (BASELINE config 5; CachedBVH::doMakeResident / doEvict, offline_bvh_cache.cpp:127-148):
  * pgpu_stage_bvh8 takes the same arguments as pgpu_upload_bvh8 but keeps the device image in pinned host memory; the
@@ -185,6 +219,7 @@ typedef struct {
     uint32_t* leaf;
     float *u, *v;
     uint32_t* visits;
+    uint32_t* inst; /* may be NULL. The instance a hit went through (leaf-object index in the traced BVH), PGPU_MISS = none */
 } pgpu_hits;
 typedef struct {
     uint64_t svdag_tests, svdag_culled; /* g_stats.svdag.numIntersectionTests / numRaysCulled */

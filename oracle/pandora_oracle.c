@@ -288,7 +288,25 @@ static inline const float* tri_vertex(const orc_mesh* m, uint32_t prim, int k)
     return m->pos + 3u * (size_t)m->idx[3u * (size_t)prim + (unsigned)k];
 }
 
-/* wive_bvh8_impl.h:272-280 + offline_bvh_cache.cpp:42-53 (Primitive alternative) */
+/* Transform::transformToLocal, graphics_core/transform.cpp:40-45: origin = inverse * (o, 1), direction = inverse * (d, 0),
+ * tnear / tfar unchanged. glm's mat4 * vec4 adds the four column products as (c0 x + c1 y) + (c2 z + c3 w) (glm is not in the
+ * container: restated from its published source, type_mat4x4.inl). */
+void orc_ray_to_local(const float m[12], const orc_ray* in, orc_ray* out)
+{
+    for (int i = 0; i < 3; i++) {
+        const float* row = m + 4 * i;
+        out->o[i] = (row[0] * in->o[0] + row[1] * in->o[1]) + (row[2] * in->o[2] + row[3] * 1.0f);
+        out->d[i] = (row[0] * in->d[0] + row[1] * in->d[1]) + (row[2] * in->d[2] + row[3] * 0.0f);
+    }
+    out->tnear = in->tnear;
+    out->tfar = in->tfar;
+}
+
+/* wive_bvh8_impl.h:272-280 + offline_bvh_cache.cpp:42-66. Primitive alternative: the triangle test. Instance alternative
+ * (:54-65): the nested BVH's intersect. The reference hands the nested traversal the UNTRANSFORMED ray -- the offline path is
+ * unfinished there; what its other acceleration structures do for the same scene graph
+ * (batching_acceleration_structure.h:411-422, embree_acceleration_structure.h:143-153) is restated here: the ray goes to the
+ * instance's local space with Transform::transformToLocal, t keeps its meaning. REF-UNPINNED. */
 static int bvh8_leaf(const orc_bvh8* b, int tri_mode, uint32_t handle, orc_ray* r, orc_hit* h, orc_counters* c)
 {
     const uint32_t* ids = b->leaf_idx + H_INDEX(handle);
@@ -296,6 +314,23 @@ static int bvh8_leaf(const orc_bvh8* b, int tri_mode, uint32_t handle, orc_ray* 
     int hit = 0;
     for (uint32_t i = 0; i < count; i++) {
         uint32_t obj = ids[i];
+        if (b->inst && b->inst[obj].child) {
+            orc_ray local;
+            orc_hit nested;
+            orc_ray_to_local(b->inst[obj].world_to_local, r, &local);
+            if (orc_bvh8_intersect(b->inst[obj].child, tri_mode, &local, &nested, c)) {
+                hit = 1;
+                r->tfar = local.tfar;
+                if (h) {
+                    h->t = local.tfar;
+                    h->obj = nested.obj;
+                    h->u = nested.u;
+                    h->v = nested.v;
+                    h->inst = obj;
+                }
+            }
+            continue;
+        }
         uint32_t prim = b->obj_prim ? b->obj_prim[obj] : obj;
         float u, v;
         if (c)
@@ -308,6 +343,7 @@ static int bvh8_leaf(const orc_bvh8* b, int tri_mode, uint32_t handle, orc_ray* 
                 h->obj = obj;
                 h->u = u;
                 h->v = v;
+                h->inst = ORC_MISS;
             }
         }
     }
@@ -390,6 +426,15 @@ int orc_bvh8_intersect_any(const orc_bvh8* b, int tri_mode, orc_ray* r, orc_coun
             const uint32_t* ids = b->leaf_idx + H_INDEX(handle);
             const uint32_t count = H_LEAF_COUNT(handle);
             for (uint32_t i = 0; i < count; i++) {
+                if (b->inst && b->inst[ids[i]].child) { /* offline_bvh_cache.cpp:74-77, ray taken to local space (see bvh8_leaf) */
+                    orc_ray local;
+                    orc_ray_to_local(b->inst[ids[i]].world_to_local, r, &local);
+                    if (orc_bvh8_intersect_any(b->inst[ids[i]].child, tri_mode, &local, c)) {
+                        r->tfar = -INFINITY;
+                        return 1;
+                    }
+                    continue;
+                }
                 uint32_t prim = b->obj_prim ? b->obj_prim[ids[i]] : ids[i];
                 float u, v;
                 if (c)
@@ -667,6 +712,7 @@ int orc_scene_intersect(const orc_scene* s, int tri_mode, int svdag_lanes, orc_r
     int hit = 0;
     if (h) {
         h->obj = ORC_MISS;
+        h->inst = ORC_MISS;
         h->leaf = 0;
         h->u = h->v = 0.0f;
     }
@@ -714,7 +760,7 @@ typedef struct {
     const float* rays;
     size_t n, lo, hi;
     float *t, *u, *v;
-    uint32_t *obj, *leaf, *anyhit, *visits;
+    uint32_t *obj, *leaf, *anyhit, *visits, *inst;
     orc_counters c;
 } job_t;
 
@@ -759,6 +805,7 @@ static void* job_run(void* p)
         } else {
             orc_hit h;
             h.obj = ORC_MISS;
+            h.inst = ORC_MISS;
             h.leaf = 0;
             h.u = h.v = 0.0f;
             uint64_t before = j->c.leaf_visits;
@@ -772,6 +819,8 @@ static void* job_run(void* p)
                 j->leaf[i] = h.leaf;
             j->u[i] = h.u;
             j->v[i] = h.v;
+            if (j->inst)
+                j->inst[i] = h.obj == ORC_MISS ? ORC_MISS : h.inst;
             if (j->visits)
                 j->visits[i] = (uint32_t)(j->c.leaf_visits - before);
         }
@@ -817,6 +866,12 @@ static void run_jobs(job_t* proto, size_t n, int n_threads, orc_counters* c)
 void orc_bvh8_trace(const orc_bvh8* b, int any_hit, int tri_mode, const float* rays, size_t n,
     float* t, uint32_t* obj, float* u, float* v, uint32_t* anyhit, orc_counters* c, int n_threads)
 {
+    orc_bvh8_trace_inst(b, any_hit, tri_mode, rays, n, t, obj, u, v, anyhit, NULL, c, n_threads);
+}
+
+void orc_bvh8_trace_inst(const orc_bvh8* b, int any_hit, int tri_mode, const float* rays, size_t n,
+    float* t, uint32_t* obj, float* u, float* v, uint32_t* anyhit, uint32_t* inst, orc_counters* c, int n_threads)
+{
     job_t j;
     memset(&j, 0, sizeof(j));
     j.kind = 0;
@@ -830,11 +885,19 @@ void orc_bvh8_trace(const orc_bvh8* b, int any_hit, int tri_mode, const float* r
     j.u = u;
     j.v = v;
     j.anyhit = anyhit;
+    j.inst = inst;
     run_jobs(&j, n, n_threads, c);
 }
 
 void orc_scene_trace(const orc_scene* s, int any_hit, int tri_mode, int svdag_lanes, const float* rays, size_t n,
     float* t, uint32_t* obj, uint32_t* leaf, float* u, float* v, uint32_t* anyhit, uint32_t* visits,
+    orc_counters* c, int n_threads)
+{
+    orc_scene_trace_inst(s, any_hit, tri_mode, svdag_lanes, rays, n, t, obj, leaf, u, v, anyhit, visits, NULL, c, n_threads);
+}
+
+void orc_scene_trace_inst(const orc_scene* s, int any_hit, int tri_mode, int svdag_lanes, const float* rays, size_t n,
+    float* t, uint32_t* obj, uint32_t* leaf, float* u, float* v, uint32_t* anyhit, uint32_t* visits, uint32_t* inst,
     orc_counters* c, int n_threads)
 {
     job_t j;
@@ -853,6 +916,7 @@ void orc_scene_trace(const orc_scene* s, int any_hit, int tri_mode, int svdag_la
     j.v = v;
     j.anyhit = anyhit;
     j.visits = visits;
+    j.inst = inst;
     run_jobs(&j, n, n_threads, c);
 }
 

@@ -53,6 +53,7 @@ typedef struct {
     uint32_t obj;  /* leaf-object index inside the BVH8, ORC_MISS = miss */
     uint32_t leaf; /* top-level leaf (batching point) index, 0 if single level */
     float u, v;
+    uint32_t inst; /* leaf-object index of the instance the hit went through, ORC_MISS = none (obj then indexes the instance's BVH) */
 } orc_hit;
 
 /* indexed triangle mesh, triangle.h:78-87 */
@@ -61,13 +62,22 @@ typedef struct {
     const uint32_t* idx; /* nt*3 */
 } orc_mesh;
 
-/* one bottom-level BVH8 over leaf objects; leaf object j = triangle obj_prim[j] of mesh */
+/* OfflineBVHLeaf::Instance (offline_bvh_cache.h:18-39): a leaf object that is a whole other BVH under a transform.
+ * child == NULL marks a leaf object that is a primitive. world_to_local = rows 0..2 of Transform::m_inverseMatrix (row-major 3x4). */
+struct orc_bvh8_s;
 typedef struct {
+    const struct orc_bvh8_s* child;
+    float world_to_local[12];
+} orc_instance;
+
+/* one bottom-level BVH8 over leaf objects; leaf object j = triangle obj_prim[j] of mesh, or inst[j] when that is an instance */
+typedef struct orc_bvh8_s {
     const orc_bvh8_node* nodes;
     const uint32_t* leaf_idx;
     uint32_t root;
     const uint32_t* obj_prim; /* n_objs, may be NULL (identity) */
     orc_mesh mesh;
+    const orc_instance* inst; /* n_objs or NULL (no instances) */
 } orc_bvh8;
 
 /* sparse_voxel_dag.h:70-78 */
@@ -150,6 +160,16 @@ void orc_bvh8_trace(const orc_bvh8* b, int any_hit, int tri_mode, const float* r
 void orc_scene_trace(const orc_scene* s, int any_hit, int tri_mode, int svdag_lanes, const float* rays, size_t n,
     float* t, uint32_t* obj, uint32_t* leaf, float* u, float* v, uint32_t* anyhit, uint32_t* visits,
     orc_counters* c, int n_threads);
+
+/* The same with the instance id of every hit (ORC_MISS where the hit is a primitive of the traced BVH itself). */
+void orc_bvh8_trace_inst(const orc_bvh8* b, int any_hit, int tri_mode, const float* rays, size_t n,
+    float* t, uint32_t* obj, float* u, float* v, uint32_t* anyhit, uint32_t* inst, orc_counters* c, int n_threads);
+void orc_scene_trace_inst(const orc_scene* s, int any_hit, int tri_mode, int svdag_lanes, const float* rays, size_t n,
+    float* t, uint32_t* obj, uint32_t* leaf, float* u, float* v, uint32_t* anyhit, uint32_t* visits, uint32_t* inst,
+    orc_counters* c, int n_threads);
+/* Transform::transformToLocal (graphics_core/transform.cpp:40-45) with glm's mat4 * vec4 association
+ * ((m0 x + m1 y) + (m2 z + m3 w)); tnear / tfar are kept: the parameter t means the same in both spaces. */
+void orc_ray_to_local(const float world_to_local[12], const orc_ray* in, orc_ray* out);
 
 /* brute force over all triangles with the same leaf test; independent of any tree */
 void orc_brute_trace(const orc_mesh* m, size_t n_tris, int tri_mode, const float* rays, size_t n,

@@ -381,7 +381,7 @@ void ref_bvh8_trace(const orc_bvh8* b, int any_hit, int tri_mode, const float* r
         if (any_hit) {
             anyhit[i] = walk8(*b, tri_mode, true, r, nullptr) ? 1u : 0u;
         } else {
-            orc_hit h { 0.0f, ORC_MISS, 0u, 0.0f, 0.0f };
+            orc_hit h { 0.0f, ORC_MISS, 0u, 0.0f, 0.0f, ORC_MISS };
             walk8(*b, tri_mode, false, r, &h);
             t[i] = r.tfar;
             obj[i] = h.obj;
@@ -405,7 +405,7 @@ void ref_scene_trace(const orc_scene* s, int any_hit, int tri_mode, const float*
         orc_ray r { { rays[i], rays[n + i], rays[2 * n + i] }, { rays[3 * n + i], rays[4 * n + i], rays[5 * n + i] }, rays[6 * n + i], rays[7 * n + i] };
         uint32_t node = s->root, at = 0, nvis = 0;
         uint64_t stack = 0xFFFFFFFFFFFFFFFFull;
-        orc_hit h { 0.0f, ORC_MISS, 0u, 0.0f, 0.0f };
+        orc_hit h { 0.0f, ORC_MISS, 0u, 0.0f, 0.0f, ORC_MISS };
         bool shadowed = false;
         while (walk4(*s, any_hit != 0, r, node, stack, at, c)) {
             ++nvis;

@@ -63,6 +63,51 @@ def build_bvh8(pos: np.ndarray, idx: np.ndarray, prim_ids: np.ndarray | None = N
         L.pgpu_host_bvh8_free(h)
 
 
+def build_bvh8_boxes(bounds: np.ndarray, alone: np.ndarray | None = None, max_leaf: int = 4) -> HostBvh8:
+    """BVH8 over arbitrary leaf objects given by their bounds [n, 6]; object j is leaf object j. alone[j] != 0 gives
+    object j a leaf of its own (instances)."""
+    L = capi.lib()
+    b = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
+    al = None if alone is None else np.ascontiguousarray(alone, np.uint8)
+    h = C.c_void_p()
+    _check(L.pgpu_build_bvh8_boxes(b.ctypes.data, b.shape[0], capi.ptr(al), max_leaf, C.byref(h)), what="pgpu_build_bvh8_boxes failed")
+    try:
+        n = C.c_size_t()
+        p = L.pgpu_host_bvh8_nodes(h, C.byref(n))
+        nodes = capi.view(p, n.value * 64, np.float32).reshape(-1, 64).copy() if n.value else np.zeros((0, 64), np.float32)
+        p = L.pgpu_host_bvh8_leaf_indices(h, C.byref(n))
+        leaf_idx = capi.view(p, n.value, np.uint32).copy()
+        return HostBvh8(nodes, leaf_idx, int(L.pgpu_host_bvh8_root(h)), int(L.pgpu_host_bvh8_depth(h)), np.arange(b.shape[0], dtype=np.uint32))
+    finally:
+        L.pgpu_host_bvh8_free(h)
+
+
+def partition_objects(bounds: np.ndarray, weights: np.ndarray | None, max_weight: int):
+    """Scene cut over objects (detail::createSubScenes, batching.cpp:38-265) -> (group_of_object uint32[n], n_groups)."""
+    L = capi.lib()
+    b = np.ascontiguousarray(bounds, np.float32).reshape(-1, 6)
+    w = None if weights is None else np.ascontiguousarray(weights, np.uint64)
+    out = np.empty(b.shape[0], np.uint32)
+    ng = C.c_uint32()
+    _check(L.pgpu_partition_objects(b.ctypes.data, capi.ptr(w), b.shape[0], int(max_weight), out.ctypes.data, C.byref(ng)), what="pgpu_partition_objects failed")
+    return out, int(ng.value)
+
+
+def transform_bounds(lo, hi, local_to_world) -> np.ndarray:
+    """Transform::transformToWorld(Bounds), graphics_core/transform.cpp:47-61: the box around the 8 transformed corners."""
+    m = np.asarray(local_to_world, np.float32).reshape(4, 4)
+    c = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float32)
+    w = c @ m.T
+    w = w[:, :3] / w[:, 3:4]
+    return np.concatenate([w.min(axis=0), w.max(axis=0)]).astype(np.float32)
+
+
+def world_to_local_rows(local_to_world) -> np.ndarray:
+    """Rows 0..2 of Transform::m_inverseMatrix (transform.cpp:7-11) as 12 floats, row-major."""
+    inv = np.linalg.inv(np.asarray(local_to_world, np.float64).reshape(4, 4))
+    return np.ascontiguousarray(inv[:3, :].astype(np.float32)).reshape(12)
+
+
 @dataclass
 class HostBvh4:
     nodes: np.ndarray       # (n_nodes, 28) float32 view of 112-byte nodes
@@ -247,6 +292,7 @@ class Context:
         if rc != capi.OK:
             raise PandoraError(rc, "pgpu_init failed (no GPU visible?)")
         self._h = h
+        self.instanced = False  # an instanced BVH was uploaded: closest-hit results then carry "inst"
 
     def close(self):
         if getattr(self, "_h", None):
@@ -286,6 +332,24 @@ class Context:
         out = C.c_uint32()
         _check(self._L.pgpu_stage_bvh8(self._h, nodes.ctypes.data, bvh.n_nodes, bvh.leaf_idx.ctypes.data, bvh.leaf_idx.size, bvh.root,
                                        objs.ctypes.data, objs.shape[0], C.byref(out)), self._h)
+        return int(out.value)
+
+    def upload_bvh8_objects(self, bvh: HostBvh8, objs: np.ndarray, instances=None, staged: bool = False) -> int:
+        """A BVH8 whose leaf objects are given explicitly: objs [n, 2] uint32 = (mesh id, primitive id), or (capi.INSTANCE, k)
+        for instance k of `instances` = list of (bvh id, world_to_local 12 floats). pgpu_upload_bvh8_instanced /
+        pgpu_stage_bvh8_instanced."""
+        objs = np.ascontiguousarray(objs, np.uint32).reshape(-1, 2)
+        inst = (capi.InstanceDesc * max(1, len(instances or [])))()
+        for k, (bid, m) in enumerate(instances or []):
+            inst[k].bvh_id = int(bid)
+            inst[k].world_to_local = (C.c_float * 12)(*[float(x) for x in np.asarray(m, np.float32).reshape(-1)[:12]])
+        nodes = np.ascontiguousarray(bvh.nodes)
+        out = C.c_uint32()
+        fn = self._L.pgpu_stage_bvh8_instanced if staged else self._L.pgpu_upload_bvh8_instanced
+        _check(fn(self._h, nodes.ctypes.data, bvh.n_nodes, bvh.leaf_idx.ctypes.data, bvh.leaf_idx.size, bvh.root, objs.ctypes.data, objs.shape[0],
+                  C.cast(inst, C.c_void_p) if instances else None, len(instances or []), C.byref(out)), self._h)
+        if instances:
+            self.instanced = True
         return int(out.value)
 
     def set_leaf_cache(self, n_bytes: int):
@@ -330,8 +394,8 @@ class Context:
         mem = capi.MEM_DEVICE if self._is_torch(rays) else capi.MEM_HOST
         if kind == capi.CLOSEST:
             if out is None:
-                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v")}
-            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), 0)
+                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v") + (("inst",) if self.instanced else ())}
+            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), 0, capi.ptr(out.get("inst")))
             _check(self._L.pgpu_trace_bvh8(self._h, bvh_id, kind, tri_mode, C.byref(r), n, mem, C.byref(h), None, stream), self._h)
         else:
             if out is None:
@@ -357,8 +421,8 @@ class Context:
         cnt = capi.Counters()
         if kind == capi.CLOSEST:
             if out is None:
-                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v", "visits")}
-            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), capi.ptr(out.get("visits")))
+                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v", "visits") + (("inst",) if self.instanced else ())}
+            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), capi.ptr(out.get("visits")), capi.ptr(out.get("inst")))
             _check(self._L.pgpu_trace(self._h, kind, tri_mode, C.byref(r), n, mem, C.byref(h), None, C.byref(cnt), stream), self._h)
         else:
             if out is None:
@@ -573,3 +637,114 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     top = build_top_bvh4(bounds)
     dags = build_svdags(pos, idx, groups, svdag_res) if svdag_res > 0 else None
     return TwoLevelScene(groups, bvhs, top, dags, bounds)
+
+
+@dataclass
+class InstancedTwoLevelScene:
+    """A scene graph with plain triangles and instanced prototypes, cut into batching points the way the reference's builder
+    does it (OfflineBatchingAccelerationStructureBuilder, offline_batching_acceleration_structure.cpp:38-57 and
+    batching.cpp:38-265, :358-422): shapes larger than primitivesPerBatchingPoint / 8 are split, the objects (sub-shapes and
+    instances) are grouped by an object-level BVH2 cut, and every group gets one bottom-level BVH8 whose leaf objects are its
+    triangles and its instances (LRUBVHSceneCache::createBVH, offline_bvh_cache.cpp:273-322)."""
+    pos: np.ndarray
+    idx: np.ndarray
+    protos: list                 # [(pos, idx)] prototype meshes in their own space
+    proto_bvhs: list             # HostBvh8 per prototype
+    inst_proto: np.ndarray
+    inst_matrix: np.ndarray      # [n, 4, 4] local-to-world
+    group_tris: list             # per batching point: triangle ids (leaf objects 0 .. nt-1)
+    group_insts: list            # per batching point: instance ids (leaf objects nt ..)
+    bvhs: list                   # HostBvh8 over the leaf objects of every batching point
+    top: HostBvh4 | None         # None: a single batching point (use it as a single-level scene)
+    dags: HostSvdags | None
+    leaf_bounds: np.ndarray
+
+    @property
+    def n_leaves(self) -> int:
+        return len(self.bvhs)
+
+    def upload(self, ctx: "Context", streamed: bool = False):
+        """Prototypes are uploaded resident (they are shared by every batching point); the batching points' own BVHs are
+        uploaded, or staged in host memory when `streamed`. Returns bvh ids per batching point (input order)."""
+        mesh_id = ctx.upload_mesh(self.pos, self.idx)
+        proto_ids = [ctx.upload_bvh8(b, ctx.upload_mesh(p, i)) for b, (p, i) in zip(self.proto_bvhs, self.protos)]
+        ids = []
+        for g, bvh in enumerate(self.bvhs):
+            tris, insts = self.group_tris[g], self.group_insts[g]
+            objs = np.empty((tris.size + insts.size, 2), np.uint32)
+            objs[:tris.size, 0] = mesh_id
+            objs[:tris.size, 1] = tris
+            objs[tris.size:, 0] = capi.INSTANCE
+            objs[tris.size:, 1] = np.arange(insts.size)
+            table = [(proto_ids[int(self.inst_proto[k])], world_to_local_rows(self.inst_matrix[k])) for k in insts]
+            ids.append(ctx.upload_bvh8_objects(bvh, objs, table, staged=streamed))
+        if self.top is not None:
+            if self.dags is not None:
+                ctx.upload_svdags(self.dags)
+            leaves = np.empty((self.n_leaves, 2), np.uint32)
+            for slot, src in enumerate(self.top.leaf_order):
+                leaves[slot, 0] = ids[int(src)]
+                leaves[slot, 1] = int(src) if self.dags is not None else capi.NO_SVDAG
+            ctx.upload_top_bvh4(self.top, leaves)
+        return ids
+
+
+def build_instanced_two_level(pos, idx, protos, inst_proto, inst_matrix, prims_per_batching_point: int, svdag_res: int = 0) -> InstancedTwoLevelScene:
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    nt = idx.shape[0]
+    inst_proto = np.asarray(inst_proto, np.int64)
+    inst_matrix = np.asarray(inst_matrix, np.float32).reshape(-1, 4, 4)
+    proto_bvhs = [build_bvh8(p, i) for p, i in protos]
+    tri_lo = pos[idx].min(axis=1)
+    tri_hi = pos[idx].max(axis=1)
+    # splitLargeSceneObjects (batching.cpp:358-422, called with primitivesPerBatchingPoint / 8): the plain geometry in pieces of that size
+    piece_of, n_pieces = partition_prims(pos, idx, max(1, prims_per_batching_point // 8))
+    piece_bounds = np.empty((n_pieces, 6), np.float32)
+    order = np.argsort(piece_of, kind="stable")
+    counts = np.bincount(piece_of, minlength=n_pieces)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    pieces = [order[starts[p]:starts[p + 1]].astype(np.uint32) for p in range(n_pieces)]
+    for p, tris in enumerate(pieces):
+        piece_bounds[p, :3] = tri_lo[tris].min(axis=0)
+        piece_bounds[p, 3:] = tri_hi[tris].max(axis=0)
+    proto_box = [(np.asarray(p, np.float32).reshape(-1, 3).min(axis=0), np.asarray(p, np.float32).reshape(-1, 3).max(axis=0)) for p, _ in protos]
+    inst_bounds = np.stack([transform_bounds(*proto_box[int(inst_proto[k])], inst_matrix[k]) for k in range(inst_proto.size)]) if inst_proto.size else np.zeros((0, 6), np.float32)
+    # createSubScenes (batching.cpp:38-265): cut over the objects. An instance weighs a fraction of its prototype: it adds
+    # traversal work to a batching point but no geometry (own heuristic; the reference counts the instanced scene's primitives).
+    obj_bounds = np.concatenate([piece_bounds, inst_bounds])
+    weights = np.concatenate([counts.astype(np.uint64), np.array([max(1, protos[int(k)][1].shape[0] // 64) for k in inst_proto], np.uint64)])
+    group_of, ng = partition_objects(obj_bounds, weights, prims_per_batching_point)
+    group_tris, group_insts, bvhs = [], [], []
+    bounds = np.empty((ng, 6), np.float32)
+    for g in range(ng):
+        members = np.nonzero(group_of == g)[0]
+        tris = np.concatenate([pieces[m] for m in members if m < n_pieces] + [np.zeros(0, np.uint32)]).astype(np.uint32)
+        insts = np.array([m - n_pieces for m in members if m >= n_pieces], np.int64)
+        boxes = np.concatenate([np.concatenate([tri_lo[tris], tri_hi[tris]], axis=1), inst_bounds[insts]]).astype(np.float32)
+        alone = np.concatenate([np.zeros(tris.size, np.uint8), np.ones(insts.size, np.uint8)])
+        group_tris.append(tris)
+        group_insts.append(insts)
+        bvhs.append(build_bvh8_boxes(boxes, alone))
+        bounds[g, :3] = boxes[:, :3].min(axis=0)
+        bounds[g, 3:] = boxes[:, 3:].max(axis=0)
+    top = build_top_bvh4(bounds) if ng >= 2 else None
+    dags = None
+    if svdag_res > 0 and top is not None:
+        # the voxeliser sees instanced geometry in world space (TriangleShape::voxelize with the instance's transform,
+        # triangle_intersect.cpp:245-249): bake each batching point's instances for this step only
+        from . import scenes
+        all_pos, all_idx, groups, base_v, base_t = [pos], [idx], [], pos.shape[0], nt
+        for g in range(ng):
+            ids = [group_tris[g].astype(np.uint32)]
+            for k in group_insts[g]:
+                baked = scenes.bake_instances([scenes.Mesh(*protos[int(inst_proto[k])])], [0], inst_matrix[k:k + 1])
+                all_pos.append(baked.pos)
+                all_idx.append(baked.idx + np.uint32(base_v))
+                ids.append(np.arange(base_t, base_t + baked.n_tris, dtype=np.uint32))
+                base_v += baked.n_verts
+                base_t += baked.n_tris
+            groups.append(np.concatenate(ids))
+        dags = build_svdags(np.concatenate(all_pos), np.concatenate(all_idx), groups, svdag_res)
+    return InstancedTwoLevelScene(pos, idx, [(np.asarray(p, np.float32), np.asarray(i, np.uint32)) for p, i in protos], proto_bvhs, inst_proto, inst_matrix,
+                                  group_tris, group_insts, bvhs, top, dags, bounds)

@@ -20,6 +20,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 MISS = 0xFFFFFFFF
 NO_SVDAG = 0xFFFFFFFF
 NO_BVH = 0xFFFFFFFF
+INSTANCE = 0xFFFFFFFF
 
 c_f32p = C.POINTER(C.c_float)
 c_u32p = C.POINTER(C.c_uint32)
@@ -31,7 +32,7 @@ class Rays(C.Structure):
 
 
 class Hits(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("t", "obj", "leaf", "u", "v", "visits")]
+    _fields_ = [(n, C.c_void_p) for n in ("t", "obj", "leaf", "u", "v", "visits", "inst")]
 
 
 class Counters(C.Structure):
@@ -49,6 +50,10 @@ class Transport(C.Structure):
 
 class LeafObj(C.Structure):
     _fields_ = [("mesh", C.c_uint32), ("prim", C.c_uint32)]
+
+
+class InstanceDesc(C.Structure):
+    _fields_ = [("bvh_id", C.c_uint32), ("world_to_local", C.c_float * 12)]
 
 
 class Leaf(C.Structure):
@@ -74,6 +79,7 @@ SYMBOLS = {
     "pgpu_host_bvh4_depth": (C.c_int, [C.c_void_p]),
     "pgpu_host_bvh4_free": (None, [C.c_void_p]),
     "pgpu_partition_prims": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "pgpu_partition_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]),
     "pgpu_build_svdags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
     "pgpu_host_svdags_words": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "pgpu_host_svdags_descs": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
@@ -91,6 +97,9 @@ SYMBOLS = {
     "pgpu_version": (C.c_char_p, []),
     "pgpu_upload_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "pgpu_upload_bvh8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pgpu_upload_bvh8_instanced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pgpu_stage_bvh8_instanced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "pgpu_build_bvh8_boxes": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "pgpu_stage_bvh8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     "pgpu_set_leaf_cache": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pgpu_upload_svdags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),

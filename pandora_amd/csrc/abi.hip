@@ -170,8 +170,9 @@ void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8T
 {
     const uint32_t need = stackEntriesForDepth(depth);
     const uint32_t window = stackWindow(need, c->stackWindow);
-    const uint32_t lanes = c->lanesPerRay;
+    const uint32_t lanes = c->hasInstances ? 4u : c->lanesPerRay; // (instance leaves: quad layout only)
     a.lanes_per_ray = lanes;
+    a.instanced = c->hasInstances ? 1u : 0u;
     a.stack_entries = window;
     a.refill_min = c->refillMin ? c->refillMin : (lanes == 2u ? 6u : 3u);
     a.n_bvhs = uint32_t(c->bvhs.size());
@@ -182,7 +183,7 @@ void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8T
     a.spill_entries = need > window ? need - window : 0u;
     a.spill = nullptr;
     const uint32_t raysPerBlock = 256u / lanes; // 4 waves x 16 (or 32) rays
-    const uint32_t maxBlocks = uint32_t(c->numCUs) * blocksPerCU(c->blocksPerCU, window, lanes);
+    const uint32_t maxBlocks = uint32_t(c->numCUs) * std::min(blocksPerCU(c->blocksPerCU, window, lanes), c->hasInstances ? 6u : 8u);
     const uint32_t wantBlocks = uint32_t((n_work + 2 * raysPerBlock - 1) / (2 * raysPerBlock));
     *blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
 }
@@ -355,7 +356,8 @@ int pgpu_upload_mesh(pgpu_ctx* c, const float* positions, size_t n_vertices, con
 
 // Validation shared by pgpu_upload_bvh8 and pgpu_stage_bvh8 + the gather of every leaf slot's triangle (see Bvh8Dev in kernels.h).
 static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
-    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, std::vector<float>& tris, Bvh8Dev& d)
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, std::vector<float>& tris,
+    std::vector<InstDev>& inst, Bvh8Dev& d)
 {
     auto bad = [&](int code, const char* what) {
         c->err = std::string(who) + ": " + what;
@@ -372,6 +374,23 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
     if (7 * depth + 8 > 96) // the 96-entry traversal stack of wive_bvh8_impl.h:74-75
         return bad(PGPU_ERR_DEPTH, "more than 12 nested inner nodes");
     tris.assign((n_indices + 1) * 12, 0.0f); // (one zero record of padding: the pair kernel reads records two at a time)
+    std::vector<uint8_t> instSlot(n_indices, 0);
+    uint32_t childDepth = 0;
+    inst.clear();
+    for (size_t i = 0; i < n_instances; ++i) {
+        const pgpu_instance& in = instances[i];
+        if (in.bvh_id >= c->bvhs.size())
+            return bad(PGPU_ERR_INVALID, "instance of an unknown bvh id");
+        if (c->bvhs[in.bvh_id].n_inst != 0)
+            return bad(PGPU_ERR_DEPTH, "instance of a BVH that holds instances itself (one level of instancing is supported)");
+        if (in.bvh_id < c->staged.size() && c->staged[in.bvh_id].host)
+            return bad(PGPU_ERR_INVALID, "instance of a BVH staged in host memory (instanced prototypes must be resident: pgpu_upload_bvh8)");
+        InstDev id {};
+        std::memcpy(id.m, in.world_to_local, sizeof(id.m));
+        id.child = in.bvh_id;
+        inst.push_back(id);
+        childDepth = std::max(childDepth, c->bvhs[in.bvh_id].depth);
+    }
     for (size_t s = 0; s < n_indices; ++s) {
         if (!slotUsed[s])
             continue; // a gap between allocator blocks: no leaf owns it, its record stays a degenerate zero triangle
@@ -379,6 +398,16 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
         if (obj >= n_objs)
             return bad(PGPU_ERR_INVALID, "leaf index beyond the leaf-object table");
         const pgpu_leafobj lo = objs[obj];
+        if (lo.mesh == PGPU_INSTANCE) {
+            // OfflineBVHLeaf::Instance: a degenerate (all-zero) triangle that never hits, tagged with its table entry
+            if (!instances || lo.prim >= n_instances)
+                return bad(PGPU_ERR_INVALID, "instance index beyond the instance table");
+            const uint32_t tag = 0x80000000u | lo.prim;
+            std::memcpy(&tris[s * 12 + 3], &obj, 4);
+            std::memcpy(&tris[s * 12 + 7], &tag, 4);
+            instSlot[s] = 1;
+            continue;
+        }
         if (lo.mesh >= c->meshes.size())
             return bad(PGPU_ERR_INVALID, "unknown mesh id");
         const HostMesh& m = c->meshes[lo.mesh];
@@ -393,11 +422,38 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
         }
         std::memcpy(&t[3], &obj, 4);
     }
+    if (n_instances) {
+        // the kernel enters an instance from a leaf that holds nothing else (the reference tests a leaf's objects one after
+        // the other, wive_bvh8_impl.h:272-280; a nested traversal in the middle of a 4-wide triangle pass has no place here)
+        auto leafOk = [&](uint32_t h) {
+            if ((h >> 29) < 4u)
+                return true;
+            const uint32_t index = h & 0x1FFFFFFFu, count = ((h >> 29) & 3u) + 1u;
+            if (count == 1u)
+                return true;
+            for (uint32_t k = 0; k < count; ++k)
+                if (instSlot[index + k])
+                    return false;
+            return true;
+        };
+        bool ok = leafOk(root_handle);
+        for (size_t i = 0; i < n_nodes && ok; ++i) {
+            if (!nodeUsed[i])
+                continue;
+            const uint32_t* kids = reinterpret_cast<const uint32_t*>(static_cast<const unsigned char*>(nodes256) + i * 256 + 192);
+            for (int k = 0; k < 8 && ok; ++k)
+                ok = leafOk(kids[k]);
+        }
+        if (!ok)
+            return bad(PGPU_ERR_INVALID, "an instance shares its leaf with other objects (build with pgpu_build_bvh8_boxes and the `alone` flag)");
+    }
     d = Bvh8Dev {};
     d.root = root_handle;
     d.n_nodes = uint32_t(n_nodes);
     d.n_slots = uint32_t(n_indices);
-    d.depth = uint32_t(depth);
+    // with instances the per-ray stack holds the outer traversal's entries below the nested one's: (7 d1 + 8) + (7 d2 + 8)
+    d.depth = n_instances ? uint32_t(depth) + childDepth + 2u : uint32_t(depth);
+    d.n_inst = uint32_t(n_instances);
     d.needs_exact = bvh8NeedsExact(static_cast<const unsigned char*>(nodes256), n_nodes, nodeUsed) ? 1u : 0u;
     return PGPU_OK;
 }
@@ -405,16 +461,31 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
 int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id)
 {
-    if (!c || !bvh_id)
+    return pgpu_upload_bvh8_instanced(c, nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, nullptr, 0, bvh_id);
+}
+
+int pgpu_upload_bvh8_instanced(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, uint32_t* bvh_id)
+{
+    if (!c || !bvh_id || (n_instances && !instances))
         return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<float> tris;
+    std::vector<InstDev> inst;
     Bvh8Dev d {};
-    int rc = prepareBvh8(c, "pgpu_upload_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, tris, d);
+    int rc = prepareBvh8(c, "pgpu_upload_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, instances, n_instances, tris, inst, d);
     if (rc != PGPU_OK)
         return rc;
     unsigned char* devNodes = nullptr;
     float* devTris = nullptr;
+    if (!inst.empty()) {
+        InstDev* devInst = nullptr;
+        rc = uploadArray(c, inst.data(), inst.size(), &devInst);
+        if (rc != PGPU_OK)
+            return rc;
+        d.inst = reinterpret_cast<const unsigned char*>(devInst);
+        c->hasInstances = true;
+    }
     rc = uploadArray(c, static_cast<const unsigned char*>(nodes256), n_nodes * 256, &devNodes);
     if (rc != PGPU_OK)
         return rc;
@@ -433,12 +504,19 @@ int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const ui
 int pgpu_stage_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id)
 {
-    if (!c || !bvh_id)
+    return pgpu_stage_bvh8_instanced(c, nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, nullptr, 0, bvh_id);
+}
+
+int pgpu_stage_bvh8_instanced(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
+    uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, uint32_t* bvh_id)
+{
+    if (!c || !bvh_id || (n_instances && !instances))
         return fail(c, PGPU_ERR_INVALID, "pgpu_stage_bvh8: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<float> tris;
+    std::vector<InstDev> inst;
     Bvh8Dev d {};
-    const int rc = prepareBvh8(c, "pgpu_stage_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, tris, d);
+    const int rc = prepareBvh8(c, "pgpu_stage_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, instances, n_instances, tris, inst, d);
     if (rc != PGPU_OK)
         return rc;
     // The cache's slots were sized for the images staged so far: start over (it is rebuilt at the next pgpu_trace), or
@@ -449,11 +527,16 @@ int pgpu_stage_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uin
     StagedBvh s;
     s.nodeBytes = (n_nodes * 256 + 255) & ~size_t(255);
     s.triBytes = (tris.size() * 4 + 255) & ~size_t(255);
-    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s.host), std::max<size_t>(s.nodeBytes + s.triBytes, 256), hipHostMallocDefault));
-    std::memset(s.host, 0, s.nodeBytes + s.triBytes);
+    s.instBytes = (inst.size() * sizeof(InstDev) + 255) & ~size_t(255);
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&s.host), std::max<size_t>(s.nodeBytes + s.triBytes + s.instBytes, 256), hipHostMallocDefault));
+    std::memset(s.host, 0, s.nodeBytes + s.triBytes + s.instBytes);
     if (n_nodes)
         std::memcpy(s.host, nodes256, n_nodes * 256);
     std::memcpy(s.host + s.nodeBytes, tris.data(), tris.size() * 4);
+    if (!inst.empty()) {
+        std::memcpy(s.host + s.nodeBytes + s.triBytes, inst.data(), inst.size() * sizeof(InstDev));
+        c->hasInstances = true;
+    }
     c->bvhs.push_back(d); // nodes / tris stay null until the BVH sits in a cache slot
     c->staged.resize(c->bvhs.size());
     c->staged.back() = s;
@@ -512,7 +595,7 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
         rc = ensure(c, c->stageRays, n * 8 * sizeof(float));
         if (rc != PGPU_OK)
             return rc;
-        rc = ensure(c, c->stageHits, n * 6 * sizeof(float));
+        rc = ensure(c, c->stageHits, n * 7 * sizeof(float));
         if (rc != PGPU_OK)
             return rc;
         float* dr = static_cast<float*>(c->stageRays.ptr);
@@ -529,6 +612,8 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
         a.u_out = hostOut[3];
         a.v_out = hostOut[4];
         a.any_out = reinterpret_cast<uint32_t*>(dh + size_t(5) * n);
+        if (kind == PGPU_CLOSEST && hits->inst)
+            a.inst_out = reinterpret_cast<uint32_t*>(dh + size_t(6) * n);
     } else if (mem == PGPU_MEM_DEVICE) {
         if (kind == PGPU_CLOSEST) {
             a.t_out = hits->t;
@@ -536,6 +621,7 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
             a.leaf_out = hits->leaf;
             a.u_out = hits->u;
             a.v_out = hits->v;
+            a.inst_out = hits->inst;
         }
         a.any_out = any_hit;
     } else {
@@ -562,6 +648,8 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
     HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
     if (c->stats)
         HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
+    if (a.inst_out && !c->hasInstances)
+        HIP_TRY(c, hipMemsetAsync(a.inst_out, 0xFF, n * 4, stream)); // (no instance leaves anywhere: the plain kernel does not write it)
     uint32_t blocks = 1;
     rc = pandora_hip::planBvh8Launch(c, c->bvhs[bvh_id].depth, n, a, &blocks);
     if (rc != PGPU_OK)
@@ -575,6 +663,8 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
             void* dst[5] = { hits->t, hits->obj, hits->leaf, hits->u, hits->v };
             for (int i = 0; i < 5; ++i)
                 HIP_TRY(c, hipMemcpyAsync(dst[i], hostOut[i], n * 4, hipMemcpyDeviceToHost, stream));
+            if (hits->inst)
+                HIP_TRY(c, hipMemcpyAsync(hits->inst, a.inst_out, n * 4, hipMemcpyDeviceToHost, stream));
             if (hits->visits)
                 std::memset(hits->visits, 0, n * 4);
         } else {

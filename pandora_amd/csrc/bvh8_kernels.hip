@@ -237,8 +237,12 @@ __device__ __forceinline__ void ldsStoreU4(lds_u8* p, uint32_t x, uint32_t y, ui
     *reinterpret_cast<__attribute__((address_space(3))) u4v*>(p) = r;
 }
 
-template <bool ANY, int TRI, bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void bvh8TraceKernel(Bvh8TraceArgs a)
+// INST = the BVHs may hold instance leaves (OfflineBVHLeaf::Instance, offline_bvh_cache.cpp:54-61): a leaf whose single object
+// is another BVH under a transform. The ray goes to the instance's space (Transform::transformToLocal, transform.cpp:40-45; t
+// keeps its meaning) and the nested traversal runs on the same per-ray stack above a floor (spBase); when the stack is back at
+// the floor the ray is reloaded and the outer traversal goes on with whatever tfar the instance left. One level of nesting.
+template <bool ANY, int TRI, bool STATS, bool INST>
+__device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs& a)
 {
     extern __shared__ __align__(16) unsigned char ldsGeneric[];
     lds_u8* const lds = (lds_u8*)ldsGeneric;
@@ -289,6 +293,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const unsigned char* nodePiece = nullptr; // nodes + this lane's piece offset
     const unsigned char* triMine = nullptr;   // tris + q * 48: triangle q of leaf slot 0
     int sp = 0, hitMark = 0;
+    // INST: floor of the nested traversal's part of the stack, the instance being traversed / of the current hit (leaf-object
+    // ids of the outer BVH; PGPU_MISS_ID = none) and the outer BVH
+    int spBase = 0;
+    uint32_t curInst = PGPU_MISS_ID, hitInst = PGPU_MISS_ID, outerBvh = 0;
     // 0 idle, 1 traversing, 2 waiting at a popped leaf (handle) for the wave's next leaf pass, 3 (inside one step
     // only) popped an inner node (handle)
     int st = 0;
@@ -299,6 +307,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     uint32_t range = blockIdx.x & 7u;     // blocks are dealt round-robin over the 8 XCDs
     bool exhausted = false;
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
+
+    // Ray set-up for the BVH `bd`: lane q of the quad brings component q of the origin (va) and of the direction (vb); lane 3
+    // brings tnear and tfar. One correctly rounded division per lane; the quad shares the 11 values with DPP.
+    auto setRay = [&](float va, float vb, const Bvh8Dev& bd) {
+        nodePiece = bd.nodes + myPiece16;
+        triMine = bd.tris + q * 48u;
+        const float inv = 1.0f / vb; // wive_bvh8_impl.h:66-68: no zero guard (lane 3: unused)
+        // rays that can meet 0 * inf (or carry inf/NaN themselves) take the x86-exact slab test
+        const float big = 3.4028234663852886e38f;
+        const bool tame = q < 3u ? (fabsf(inv) <= big && inv != 0.0f && fabsf(va) <= big) : (va == va && vb == vb);
+        shift = quadOr(q < 3u && vb > 0.0f ? qbit : 0u) * 3u; // :384-388
+        shift |= (quadOr(tame ? 0u : 1u) | (bd.needs_exact != 0u ? 1u : 0u)) << 8;
+        ox = quadBcast<0>(va);
+        oy = quadBcast<1>(va);
+        oz = quadBcast<2>(va);
+        tnear = quadBcast<3>(va);
+        dx = quadBcast<0>(vb);
+        dy = quadBcast<1>(vb);
+        dz = quadBcast<2>(vb);
+        tfar = quadBcast<3>(vb);
+        ix = quadBcast<0>(inv);
+        iy = quadBcast<1>(inv);
+        iz = quadBcast<2>(inv);
+        rdNearX = ix < 0.0f ? pairOdd : pairEven;
+        rdNearY = (iy < 0.0f ? pairOdd : pairEven) + 1024;
+        rdNearZ = (iz < 0.0f ? pairOdd : pairEven) + 2048;
+    };
 
     for (bool done = false; !done;) {
         // ------------------------------------------------------------ refill idle quads
@@ -338,32 +373,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 const uint32_t bvhId = a.work_bvh ? a.work_bvh[w] : a.fixed_bvh;
                 tag = a.work_tag ? a.work_tag[w] : 0u;
                 const Bvh8Dev bd = a.bvhs[min(bvhId, a.n_bvhs - 1u)];
-                nodePiece = bd.nodes + myPiece16;
-                triMine = bd.tris + q * 48u;
                 // lane q of the quad loads component q of the origin and of the direction (lane 3: tnear, tfar)
                 const float* const loadA = q == 0 ? a.ox : (q == 1 ? a.oy : (q == 2 ? a.oz : a.tnear));
                 const float* const loadB = q == 0 ? a.dx : (q == 1 ? a.dy : (q == 2 ? a.dz : a.tfar_in));
-                const float va = loadA[rayId], vb = loadB[rayId];
-                const float inv = 1.0f / vb; // wive_bvh8_impl.h:66-68: no zero guard (lane 3: unused)
-                // rays that can meet 0 * inf (or carry inf/NaN themselves) take the x86-exact slab test
-                const float big = 3.4028234663852886e38f;
-                const bool tame = q < 3u ? (fabsf(inv) <= big && inv != 0.0f && fabsf(va) <= big) : (va == va && vb == vb);
-                shift = quadOr(q < 3u && vb > 0.0f ? qbit : 0u) * 3u; // :384-388
-                shift |= (quadOr(tame ? 0u : 1u) | (bd.needs_exact != 0u ? 1u : 0u)) << 8;
-                ox = quadBcast<0>(va);
-                oy = quadBcast<1>(va);
-                oz = quadBcast<2>(va);
-                tnear = quadBcast<3>(va);
-                dx = quadBcast<0>(vb);
-                dy = quadBcast<1>(vb);
-                dz = quadBcast<2>(vb);
-                tfar = quadBcast<3>(vb);
-                ix = quadBcast<0>(inv);
-                iy = quadBcast<1>(inv);
-                iz = quadBcast<2>(inv);
-                rdNearX = ix < 0.0f ? pairOdd : pairEven;
-                rdNearY = (iy < 0.0f ? pairOdd : pairEven) + 1024;
-                rdNearZ = (iz < 0.0f ? pairOdd : pairEven) + 2048;
+                setRay(loadA[rayId], loadB[rayId], bd);
+                if (INST) {
+                    spBase = 0;
+                    curInst = hitInst = PGPU_MISS_ID;
+                    outerBvh = min(bvhId, a.n_bvhs - 1u);
+                }
                 hitObj = PGPU_MISS_ID;
                 hitU = hitV = 0.0f;
                 if (q == 0)
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             const bool run = st == 1;
             const int top = sp - 1;
             const int e = top - int(q);
-            const bool valid = run && e >= 0;
+            const bool valid = run && e >= (INST ? spBase : 0);
             const bool deep = __ballot(uint32_t(sp) > W) != 0; // some stack reaches beyond the LDS window
             uint2 ent = make_uint2(0u, 0u);
             if (valid) {
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             const uint32_t first = uint32_t(__builtin_ctz(m | 16u));
             const uint32_t popped = uint32_t(__builtin_amdgcn_ds_bpermute(int(quadLane0x4 + (first << 2)), int(ent.x)));
             const bool got = run && m != 0u;
-            sp = run ? (m != 0u ? top - int(first) : max(sp - 4, 0)) : sp; // (no survivor: all 4 candidates were culled)
+            sp = run ? (m != 0u ? top - int(first) : max(sp - 4, INST ? spBase : 0)) : sp; // (no survivor: all 4 candidates were culled)
             hitMark = min(hitMark, sp);
             handle = got ? popped : handle;
             st = got ? ((popped >> 29) == 2u ? 3 : 2) : st;
@@ -433,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             const bool triLane = isLeaf && q <= ((handle >> 29) & 3u); // count - 1 = low two flag bits (:378-382)
             // (t = +inf marks "no hit"; u, v and obj of such lanes are never selected)
             float tHit = __builtin_inff(), uHit = 0.0f, vHit = 0.0f, tRaw = 0.0f, ka = 0.0f, kb = 0.0f;
-            uint32_t obj = 0, pass = 0;
+            uint32_t obj = 0, pass = 0, instWord = 0;
             if (triLane) {
                 typedef float f4v __attribute__((ext_vector_type(4)));
                 typedef const __attribute__((address_space(1))) f4v* gf4;
@@ -441,6 +459,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                 const f4v r0 = t[0], r1 = t[1], r2 = t[2];
                 const float4 p0 = make_float4(r0.x, r0.y, r0.z, r0.w), p1 = make_float4(r1.x, r1.y, r1.z, r1.w), p2 = make_float4(r2.x, r2.y, r2.z, r2.w);
                 obj = __float_as_uint(r0.w);
+                if (INST)
+                    instWord = __float_as_uint(r1.w); // bit 31: this slot is an instance (its record is a degenerate triangle: no hit)
                 const TriHit th = TRI == PGPU_TRI_WATERTIGHT_ID ? triWatertight(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2)
                                                                 : triMT(ox, oy, oz, dx, dy, dz, tnear, tfar, p0, p1, p2);
                 uHit = th.u;
@@ -505,7 +525,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                         hitU = wu;
                         hitV = wv;
                         hitObj = wobj;
+                        if (INST)
+                            hitInst = curInst;
                         hitMark = sp; // everything still on the stack predates this hit
+                    }
+                }
+            }
+            if (INST) {
+                // An instance leaf holds exactly one object (checked at upload): enter its BVH. Only from the outer level
+                // (an instance inside an instance is rejected at upload).
+                const uint32_t iw = uint32_t(quadPerm<0, 0, 0, 0>(int(instWord)));
+                const uint32_t iobj = uint32_t(quadPerm<0, 0, 0, 0>(int(obj)));
+                if (isLeaf && (iw & 0x80000000u) != 0u && curInst == PGPU_MISS_ID) {
+                    const InstDev* const I = reinterpret_cast<const InstDev*>(a.bvhs[outerBvh].inst) + (iw & 0x7FFFFFFFu);
+                    const uint32_t childId = I->child;
+                    const Bvh8Dev cd = a.bvhs[min(childId, a.n_bvhs - 1u)];
+                    if (childId < a.n_bvhs && cd.nodes != nullptr) {
+                        // Transform::transformToLocal with glm's association (c0 x + c1 y) + (c2 z + c3 w): row q of the
+                        // world-to-local matrix in lane q (lane 3 carries tnear / the current tfar through)
+                        const float* const row = I->m + 4u * min(q, 2u);
+                        const float m0 = row[0], m1 = row[1], m2 = row[2], m3 = row[3];
+                        const float lo = (m0 * ox + m1 * oy) + (m2 * oz + m3 * 1.0f);
+                        const float ld = (m0 * dx + m1 * dy) + (m2 * dz + m3 * 0.0f);
+                        const float keepNear = tnear, keepFar = tfar;
+                        setRay(q == 3u ? keepNear : lo, q == 3u ? keepFar : ld, cd);
+                        spBase = sp;
+                        if (q == 0)
+                            stackStore(uint32_t(sp), make_uint2(cd.root, __float_as_uint(0.0f)));
+                        sp += 1;
+                        curInst = iobj;
                     }
                 }
             }
@@ -587,7 +635,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         }
 
         // ------------------------------------------------------------ retire rays whose stack ran dry
-        if (st == 1 && sp == 0) {
+        if (INST && st == 1 && sp == spBase && curInst != PGPU_MISS_ID) {
+            // the instance's BVH is done: back to the outer traversal with the ray as it was, except for tfar
+            const float* const loadA = q == 0 ? a.ox : (q == 1 ? a.oy : (q == 2 ? a.oz : a.tnear));
+            const float* const loadB = q == 0 ? a.dx : (q == 1 ? a.dy : (q == 2 ? a.dz : a.tfar_in));
+            const float keepFar = tfar;
+            const float vb = loadB[rayId];
+            setRay(loadA[rayId], q == 3u ? keepFar : vb, a.bvhs[outerBvh]);
+            spBase = 0;
+            curInst = PGPU_MISS_ID;
+        } else if (st == 1 && sp == 0) {
             if (q == 0) {
                 const uint32_t off = rayId << 2;
                 if (ANY) {
@@ -600,11 +657,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
                         at32(a.leaf_out, off) = tag;
                         at32(a.u_out, off) = hitU;
                         at32(a.v_out, off) = hitV;
+                        if (INST && a.inst_out)
+                            at32(a.inst_out, off) = hitInst;
                     } else if (a.init_miss) {
                         at32(a.obj_out, off) = PGPU_MISS_ID;
                         at32(a.leaf_out, off) = 0u;
                         at32(a.u_out, off) = 0.0f;
                         at32(a.v_out, off) = 0.0f;
+                        if (INST && a.inst_out)
+                            at32(a.inst_out, off) = PGPU_MISS_ID;
                     }
                 }
             }
@@ -626,6 +687,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             atomicAdd(&a.stats[5], (unsigned long long)statRefill);
         }
     }
+}
+
+template <bool ANY, int TRI, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void bvh8TraceKernel(Bvh8TraceArgs a)
+{
+    bvh8TraceBody<ANY, TRI, STATS, false>(a);
+}
+
+// the same with instance leaves (a few more registers of per-ray state: one resident block less per CU)
+template <bool ANY, int TRI, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 7))) void bvh8TraceInstKernel(Bvh8TraceArgs a)
+{
+    bvh8TraceBody<ANY, TRI, STATS, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1118,7 +1192,9 @@ hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, boo
     const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries, args.lanes_per_ray);
 #define PANDORA_LAUNCH(ANYV, TRIV, STATV)                                                                            \
     do {                                                                                                             \
-        if (args.lanes_per_ray == 2u)                                                                                \
+        if (args.instanced)                                                                                          \
+            hipLaunchKernelGGL((bvh8TraceInstKernel<ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args);       \
+        else if (args.lanes_per_ray == 2u)                                                                           \
             hipLaunchKernelGGL((bvh8TracePairKernel<ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args);       \
         else                                                                                                         \
             hipLaunchKernelGGL((bvh8TraceKernel<ANYV, TRIV, STATV>), grid, block, ldsBytes, stream, args);           \

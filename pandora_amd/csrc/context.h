@@ -18,8 +18,8 @@ struct DeviceBuffer {
 // A bottom-level BVH kept in pinned host memory and copied into an HBM cache slot when rays reach it
 // (BASELINE config 5; the reference's CachedBVH::doMakeResident / doEvict, offline_bvh_cache.cpp:127-148).
 struct StagedBvh {
-    unsigned char* host = nullptr; // pinned: the 256-byte nodes, then (256-aligned) the 48-byte triangle records
-    size_t nodeBytes = 0, triBytes = 0;
+    unsigned char* host = nullptr; // pinned: the 256-byte nodes, then (256-aligned) the 48-byte triangle records, then the instance table
+    size_t nodeBytes = 0, triBytes = 0, instBytes = 0;
     int slot = -1; // cache slot it currently occupies
 };
 struct CacheSlot {
@@ -47,6 +47,7 @@ struct pgpu_ctx {
     DeviceBuffer spill;      // global overflow of the per-ray stacks
     unsigned char* staticScratch = nullptr; // this device's copy of the static scratch array of noalloc.hip (resolved at pgpu_init)
 
+    bool hasInstances = false; // some BVH holds instance leaves: the bottom-level launches use the kernel variant that follows them
     std::vector<HostMesh> meshes;
     std::vector<pandora_hip::Bvh8Dev> bvhs; // host mirror of the device table
     std::vector<void*> owned;               // every hipMalloc'd scene buffer

@@ -25,7 +25,17 @@ struct Bvh8Dev {
     uint32_t n_slots;
     uint32_t depth;
     uint32_t needs_exact; // some child box is unordered or non-finite: always use the x86-exact slab test
-    uint32_t pad;
+    uint32_t n_inst;      // entries of `inst`
+    const unsigned char* inst; // InstDev table of the instance leaves (nullptr: every leaf object is a triangle)
+};
+
+// One instance (OfflineBVHLeaf::Instance, offline_bvh_cache.h:18-39): the BVH it shows and the world-to-local transform
+// (rows 0..2 of Transform::m_inverseMatrix, row-major). The triangle record of an instance slot is a degenerate triangle
+// that carries the leaf-object id in p0.w and 0x80000000 | index into this table in p1.w.
+struct InstDev {
+    float m[12];
+    uint32_t child;
+    uint32_t pad[3];
 };
 
 struct Bvh8TraceArgs {
@@ -42,6 +52,8 @@ struct Bvh8TraceArgs {
     uint32_t* leaf_out;
     float *u_out, *v_out;
     uint32_t* any_out;
+    uint32_t* inst_out; // instance (leaf-object id in the traced BVH) a hit went through, PGPU_MISS_ID = none; may be nullptr
+    uint32_t instanced; // 1: some BVH of the table holds instance leaves -> the kernel variant that follows them (quad layout)
     uint32_t* cursor; // 8 work cursors (one per XCD group of blocks), 32 bytes apart, zeroed before launch
     uint32_t range_size; // work items per cursor
     uint32_t chunk;

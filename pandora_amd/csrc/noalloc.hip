@@ -107,6 +107,7 @@ int pgpu_trace_bvh8_noalloc(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode
         a.leaf_out = hits->leaf;
         a.u_out = hits->u;
         a.v_out = hits->v;
+        a.inst_out = hits->inst;
     }
     a.any_out = any_hit;
     a.cursor = reinterpret_cast<uint32_t*>(base);
@@ -127,6 +128,8 @@ int pgpu_trace_bvh8_noalloc(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode
         a.spill = reinterpret_cast<unsigned long long*>(base + kCursorBytes);
     }
     HIP_TRY(c, hipMemsetAsync(base, 0, kCursorBytes, stream));
+    if (a.inst_out && !c->hasInstances)
+        HIP_TRY(c, hipMemsetAsync(a.inst_out, 0xFF, n * 4, stream));
     if (c->stats)
         HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
     HIP_TRY(c, hipEventRecord(c->ev0, stream));

@@ -157,6 +157,8 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: no bottom-level BVH is resident");
     if (c->nStaged > 0)
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
+    if (c->hasInstances)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_leaf_records: this context holds instanced BVHs; instance hits are not routed between ranks yet");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
     HIP_TRY(c, hipEventRecord(c->ev0, stream));

@@ -361,6 +361,8 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: no owner table for this top level (pgpu_set_leaf_owners)");
     if (c->nStaged > 0)
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
+    if (c->hasInstances)
+        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: this context holds instanced BVHs; instance hits are not routed between ranks yet");
     if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_sharded: kind must be PGPU_CLOSEST or PGPU_ANY");
     if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)

@@ -30,7 +30,7 @@ int ensureLeafCache(pgpu_ctx* c)
     size_t slotBytes = 0;
     for (const StagedBvh& s : c->staged)
         if (s.host)
-            slotBytes = std::max(slotBytes, s.nodeBytes + s.triBytes);
+            slotBytes = std::max(slotBytes, s.nodeBytes + s.triBytes + s.instBytes);
     slotBytes = std::max<size_t>(alignUp(slotBytes), 256);
     size_t nSlots = c->nStaged;
     if (c->cacheBudget) {
@@ -79,15 +79,16 @@ int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* c
     if (slot.lastLaunch >= 0)
         HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->launchEvents[size_t(slot.lastLaunch)], 0));
     unsigned char* dst = c->cacheArena + size_t(victim) * c->slotBytes;
-    HIP_TRY(c, hipMemcpyAsync(dst, s.host, s.nodeBytes + s.triBytes, hipMemcpyHostToDevice, c->copyStream));
+    HIP_TRY(c, hipMemcpyAsync(dst, s.host, s.nodeBytes + s.triBytes + s.instBytes, hipMemcpyHostToDevice, c->copyStream));
     c->bvhs[id].nodes = dst;
     c->bvhs[id].tris = dst + s.nodeBytes;
+    c->bvhs[id].inst = s.instBytes ? dst + s.nodeBytes + s.triBytes : nullptr;
     s.slot = victim;
     slot.bvh = int(id);
     slot.lastUse = ++c->useClock;
     pinned[size_t(victim)] = 1;
     c->counters.leaf_loads += 1;
-    c->counters.streamed_bytes += s.nodeBytes + s.triBytes;
+    c->counters.streamed_bytes += s.nodeBytes + s.triBytes + s.instBytes;
     *copied = true;
     return PGPU_OK;
 }
@@ -266,7 +267,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     size_t oRays = 0, oHits = 0;
     if (mem == PGPU_MEM_HOST) {
         oRays = carve(n * 8 * 4);
-        oHits = carve(n * 7 * 4);
+        oHits = carve(n * 8 * 4);
     }
     int rc = ensure(c, c->work, off);
     if (rc != PGPU_OK)
@@ -286,7 +287,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     unsigned long long* dCounters = reinterpret_cast<unsigned long long*>(wb + oCounters);
 
     float* dT = nullptr;
-    uint32_t *dObj = nullptr, *dLeaf = nullptr, *dVisits = nullptr, *dAny = nullptr;
+    uint32_t *dObj = nullptr, *dLeaf = nullptr, *dVisits = nullptr, *dAny = nullptr, *dInst = nullptr;
+    const bool wantInst = kind == PGPU_CLOSEST && hits && hits->inst;
     float *dU = nullptr, *dV = nullptr;
     if (mem == PGPU_MEM_HOST) {
         float* dr = reinterpret_cast<float*>(wb + oRays);
@@ -302,7 +304,9 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         dV = dh + 4 * n;
         dVisits = wantVisits ? reinterpret_cast<uint32_t*>(dh + 5 * n) : nullptr;
         dAny = reinterpret_cast<uint32_t*>(dh + 6 * n);
+        dInst = wantInst ? reinterpret_cast<uint32_t*>(dh + 7 * n) : nullptr;
     } else {
+        dInst = wantInst ? hits->inst : nullptr;
         if (kind == PGPU_CLOSEST) {
             dT = hits->t;
             dObj = hits->obj;
@@ -318,6 +322,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     HIP_TRY(c, hipMemsetAsync(dCounters, 0, 256, stream));
     if (c->stats)
         HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
+    if (dInst)
+        HIP_TRY(c, hipMemsetAsync(dInst, 0xFF, n * 4, stream)); // a hit through an instance overwrites it, a later plain hit resets it
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     HIP_TRY(c, launchInitState(uint32_t(n), c->top.root, dNode, dStack, rp[7], kind == PGPU_CLOSEST ? dT : nullptr, dObj, dLeaf, dU, dV,
                    dVisits, kind == PGPU_ANY ? dAny : nullptr, streamBlocks, stream));
@@ -361,6 +367,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ba.u_out = dU;
     ba.v_out = dV;
     ba.any_out = dAny;
+    ba.inst_out = dInst;
     ba.cursor = c->cursor;
     ba.chunk = c->chunk;
     ba.init_miss = 0;
@@ -497,6 +504,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         }
         if (wantVisits)
             HIP_TRY(c, hipMemcpyAsync(hits->visits, dVisits, n * 4, hipMemcpyDeviceToHost, stream));
+        if (wantInst)
+            HIP_TRY(c, hipMemcpyAsync(hits->inst, dInst, n * 4, hipMemcpyDeviceToHost, stream));
     }
     unsigned long long cnt[2] = { 0, 0 };
     HIP_TRY(c, hipMemcpyAsync(cnt, dCounters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
@@ -648,6 +657,7 @@ int pgpu_trace_leaves(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
         ba.leaf_out = hits->leaf;
         ba.u_out = hits->u;
         ba.v_out = hits->v;
+        ba.inst_out = hits->inst;
     }
     ba.any_out = any_hit;
     ba.cursor = c->cursor;

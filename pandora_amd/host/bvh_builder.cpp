@@ -54,6 +54,7 @@ struct Item {
     Box box;
     float c[3];
     uint32_t id;
+    bool alone = false; // must sit in a leaf of its own (an instance: its leaf is a nested traversal, not a triangle test)
 };
 
 struct Part {
@@ -61,6 +62,19 @@ struct Part {
     Box box;
     size_t count() const { return end - begin; }
 };
+
+// a part that may become one leaf: at most maxLeaf objects, and an object that must be alone is alone
+bool leafable(const std::vector<Item>& items, size_t b, size_t e, size_t maxLeaf)
+{
+    if (e - b <= 1)
+        return true;
+    if (e - b > maxLeaf)
+        return false;
+    for (size_t i = b; i < e; ++i)
+        if (items[i].alone)
+            return false;
+    return true;
+}
 
 Box boundsOf(const std::vector<Item>& items, size_t b, size_t e)
 {
@@ -155,7 +169,7 @@ std::vector<Part> makeParts(std::vector<Item>& items, size_t begin, size_t end, 
         float bestArea = -1.0f;
         bool over = false;
         for (size_t i = 0; i < parts.size(); ++i) {
-            if (parts[i].count() <= maxLeaf)
+            if (leafable(items, parts[i].begin, parts[i].end, maxLeaf))
                 continue;
             const bool isOver = double(parts[i].count()) > capacity;
             const float a = parts[i].box.halfArea();
@@ -182,9 +196,9 @@ std::vector<Part> makeParts(std::vector<Item>& items, size_t begin, size_t end, 
         parts.push_back({ begin, end, boundsOf(items, begin, end) });
         for (;;) {
             int pick = -1;
-            size_t most = maxLeaf;
+            size_t most = 0;
             for (size_t i = 0; i < parts.size(); ++i)
-                if (parts[i].count() > most) {
+                if (parts[i].count() > most && !leafable(items, parts[i].begin, parts[i].end, maxLeaf)) {
                     most = parts[i].count();
                     pick = int(i);
                 }
@@ -256,7 +270,7 @@ struct Bvh8Builder {
     // depth = number of inner nodes above this one
     uint32_t build(const Part& whole, int depth)
     {
-        if (whole.count() <= maxLeaf)
+        if (leafable(items, whole.begin, whole.end, maxLeaf))
             return emitLeaf(whole);
         maxDepthSeen = std::max(maxDepthSeen, depth + 1);
         // a child at inner depth d+1 may hold at most maxLeaf * 8^(kMax - (d+1)) items
@@ -409,6 +423,35 @@ int pgpu_build_bvh8(const float* positions, size_t n_vertices, const uint32_t* i
     return PGPU_OK;
 }
 
+int pgpu_build_bvh8_boxes(const float* bounds6, size_t n_objects, const uint8_t* alone, uint32_t max_leaf, pgpu_host_bvh8** out)
+{
+    if (!bounds6 || !out || n_objects == 0 || max_leaf < 1 || max_leaf > 4 || n_objects >= (1u << 29) - 1u)
+        return PGPU_ERR_INVALID;
+    Bvh8Builder b;
+    b.maxLeaf = max_leaf;
+    b.items.resize(n_objects);
+    for (size_t j = 0; j < n_objects; ++j) {
+        Item& it = b.items[j];
+        for (int a = 0; a < 3; ++a) {
+            it.box.lo[a] = bounds6[6 * j + size_t(a)];
+            it.box.hi[a] = bounds6[6 * j + 3 + size_t(a)];
+            if (!(it.box.lo[a] <= it.box.hi[a]))
+                return PGPU_ERR_INVALID;
+            it.c[a] = 0.5f * (it.box.lo[a] + it.box.hi[a]);
+        }
+        it.id = uint32_t(j);
+        it.alone = alone && alone[j];
+    }
+    Part whole { 0, n_objects, boundsOf(b.items, 0, n_objects) };
+    auto* r = new pgpu_host_bvh8();
+    r->v.root = b.build(whole, 0);
+    r->v.nodes = std::move(b.nodes);
+    r->v.leafIdx = std::move(b.leafIdx);
+    r->v.depth = b.maxDepthSeen;
+    *out = r;
+    return PGPU_OK;
+}
+
 const void* pgpu_host_bvh8_nodes(const pgpu_host_bvh8* b, size_t* n_nodes)
 {
     if (n_nodes)
@@ -493,6 +536,54 @@ int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32
         if (e - b <= max_prims) {
             for (size_t i = b; i < e; ++i)
                 group_of_prim[items[i].id] = g;
+            if (e > b)
+                ++g;
+            continue;
+        }
+        const size_t m = splitPart(items, b, e, false);
+        todo.push_back({ m, e });
+        todo.push_back({ b, m });
+    }
+    *n_groups = g;
+    return PGPU_OK;
+}
+
+// The scene cut of the reference at the level it makes it: over scene OBJECTS (shapes and instanced sub-scenes), not over
+// triangles. detail::createSubScenes (batching.cpp:38-265) builds an Embree BVH2 over the objects' bounds and cuts it where
+// a subtree holds <= primitivesPerBatchingPoint primitives (:161-224); the same rule on a binned-SAH BVH2 here. An object
+// heavier than the limit ends up alone (the reference splits such shapes beforehand, splitLargeSceneObjects,
+// batching.cpp:358-422 -- pgpu_partition_prims over the shape's triangles does that here).
+int pgpu_partition_objects(const float* bounds6, const uint64_t* weights, size_t n_objects, uint64_t max_weight, uint32_t* group_of_object,
+    uint32_t* n_groups)
+{
+    if (!bounds6 || !group_of_object || !n_groups || max_weight == 0)
+        return PGPU_ERR_INVALID;
+    std::vector<Item> items(n_objects);
+    for (size_t j = 0; j < n_objects; ++j) {
+        Item& it = items[j];
+        for (int a = 0; a < 3; ++a) {
+            it.box.lo[a] = bounds6[6 * j + size_t(a)];
+            it.box.hi[a] = bounds6[6 * j + 3 + size_t(a)];
+            if (!(it.box.lo[a] <= it.box.hi[a]))
+                return PGPU_ERR_INVALID;
+            it.c[a] = 0.5f * (it.box.lo[a] + it.box.hi[a]);
+        }
+        it.id = uint32_t(j);
+    }
+    auto weightOf = [&](size_t b, size_t e) {
+        uint64_t w = 0;
+        for (size_t i = b; i < e; ++i)
+            w += weights ? weights[items[i].id] : 1u;
+        return w;
+    };
+    std::vector<std::pair<size_t, size_t>> todo { { 0, n_objects } };
+    uint32_t g = 0;
+    while (!todo.empty()) {
+        auto [b, e] = todo.back();
+        todo.pop_back();
+        if (e - b <= 1 || weightOf(b, e) <= max_weight) {
+            for (size_t i = b; i < e; ++i)
+                group_of_object[items[i].id] = g;
             if (e > b)
                 ++g;
             continue;

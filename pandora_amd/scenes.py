@@ -256,6 +256,60 @@ def g_city(n_blocks_side: int, tris_per_block: int, seed: int = 11) -> Mesh:
     return merge(parts)
 
 
+def tree_prototype(seed: int, detail: int = 2) -> Mesh:
+    """A small tree in its own space (base at the origin, ~4 units tall): a trunk and a few foliage blobs. `detail` is the
+    icosphere level of the blobs (2 -> ~1.2 k triangles, 3 -> ~4.5 k)."""
+    rng = np.random.default_rng(seed)
+    parts = [cylinder((0.0, 0.0, 0.0), 0.15 + 0.1 * rng.random(), 2.0 + rng.random(), 10, 4)]
+    for _ in range(3 + int(rng.integers(0, 3))):
+        c = rng.uniform((-0.8, 1.8, -0.8), (0.8, 3.6, 0.8))
+        parts.append(icosphere(c, 0.5 + 0.6 * rng.random(), detail))
+    return merge(parts)
+
+
+def g_landscape(n_prototypes: int = 8, n_instances: int = 1500, terrain_n: int = 96, size: float = 120.0, detail: int = 2, seed: int = 5):
+    """Instanced-landscape stand-in (BASELINE configs[4], SURVEY G-landscape): a heightfield terrain (plain triangles) and
+    `n_instances` placements of `n_prototypes` tree meshes. Returns (terrain Mesh, [prototype Mesh], proto id per instance
+    int32[n], local-to-world matrices float32[n, 4, 4]): rotation about y, uniform scale, translation onto the terrain."""
+    amp = 0.03 * size
+
+    def height(s, t):
+        return amp * _noise(s, t, seed, 4)
+
+    terrain = grid_patch((0, 0, 0), (size, 0, 0), (0, 0, size), terrain_n, terrain_n,
+                         displace=lambda s, t: np.stack([np.zeros_like(s), height(s, t), np.zeros_like(s)], 1))
+    protos = [tree_prototype(seed * 1000 + i, detail) for i in range(n_prototypes)]
+    rng = np.random.default_rng(seed + 1)
+    st = rng.uniform(0.02, 0.98, (n_instances, 2))
+    ang = rng.uniform(0, 2 * np.pi, n_instances)
+    scale = rng.uniform(0.6, 1.6, n_instances)
+    proto = rng.integers(0, n_prototypes, n_instances).astype(np.int32)
+    y = height(st[:, 0], st[:, 1])
+    m = np.zeros((n_instances, 4, 4), np.float64)
+    m[:, 0, 0] = scale * np.cos(ang)
+    m[:, 0, 2] = scale * np.sin(ang)
+    m[:, 1, 1] = scale
+    m[:, 2, 0] = -scale * np.sin(ang)
+    m[:, 2, 2] = scale * np.cos(ang)
+    m[:, 0, 3] = st[:, 0] * size
+    m[:, 1, 3] = y - 0.05
+    m[:, 2, 3] = st[:, 1] * size
+    m[:, 3, 3] = 1.0
+    return terrain, protos, proto, m.astype(np.float32)
+
+
+def bake_instances(protos, proto, matrices) -> Mesh:
+    """The instanced geometry as plain world-space triangles (Transform::transformPointToWorld per vertex,
+    transform.cpp:18-22): what the voxeliser sees (triangle_intersect.cpp:245-249) and a brute-force cross-check."""
+    out = []
+    for k in range(len(proto)):
+        pm = protos[int(proto[k])]
+        m = matrices[k].astype(np.float32)
+        p = np.concatenate([pm.pos, np.ones((pm.n_verts, 1), np.float32)], axis=1) @ m.T
+        out.append(Mesh(p[:, :3] / p[:, 3:4], pm.idx))
+    return merge(out)
+
+
 # ----------------------------------------------------------------------------- ray sets (SoA [8][n])
 def _normalize(v):
     return v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)

@@ -26,7 +26,12 @@ class Mesh(C.Structure):
 
 
 class Bvh8(C.Structure):
-    _fields_ = [("nodes", C.c_void_p), ("leaf_idx", C.c_void_p), ("root", C.c_uint32), ("obj_prim", C.c_void_p), ("mesh", Mesh)]
+    _fields_ = [("nodes", C.c_void_p), ("leaf_idx", C.c_void_p), ("root", C.c_uint32), ("obj_prim", C.c_void_p), ("mesh", Mesh), ("inst", C.c_void_p)]
+
+
+class Instance(C.Structure):
+    """orc_instance: child BVH (NULL = the leaf object is a primitive) + world-to-local 3x4 (row-major)."""
+    _fields_ = [("child", C.c_void_p), ("world_to_local", C.c_float * 12)]
 
 
 class Svdag(C.Structure):
@@ -76,6 +81,8 @@ def oracle() -> C.CDLL:
         _orc.orc_sign_shift.restype = C.c_uint32
         _orc.orc_bvh8_trace.argtypes = [C.POINTER(Bvh8), C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 5 + [C.POINTER(Counters), C.c_int]
         _orc.orc_scene_trace.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(Counters), C.c_int]
+        _orc.orc_bvh8_trace_inst.argtypes = [C.POINTER(Bvh8), C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6 + [C.POINTER(Counters), C.c_int]
+        _orc.orc_scene_trace_inst.argtypes = [C.POINTER(Scene), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 8 + [C.POINTER(Counters), C.c_int]
         _orc.orc_brute_trace.argtypes = [C.POINTER(Mesh), C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     return _orc
 
@@ -112,14 +119,23 @@ def make_ray(o, d, tnear=0.0, tfar=3.4028234663852886e38) -> Ray:
 class OracleBvh8:
     """Keeps the numpy arrays alive behind an orc_bvh8."""
 
-    def __init__(self, nodes, leaf_idx, root, prim_ids, pos, idx):
+    def __init__(self, nodes, leaf_idx, root, prim_ids, pos, idx, instances=None):
+        """instances: optional list over leaf objects of None (primitive) or (OracleBvh8 child, world_to_local 3x4)."""
         self.nodes = np.ascontiguousarray(nodes, np.float32)
         self.leaf_idx = np.ascontiguousarray(leaf_idx, np.uint32)
         self.prim_ids = np.ascontiguousarray(prim_ids, np.uint32)
         self.pos = np.ascontiguousarray(pos, np.float32)
         self.idx = np.ascontiguousarray(idx, np.uint32)
+        self.inst = None
+        if instances is not None:
+            self.children = [i[0] for i in instances if i is not None]  # keep them alive
+            self.inst = (Instance * len(instances))()
+            for j, i in enumerate(instances):
+                if i is not None:
+                    self.inst[j].child = C.cast(C.pointer(i[0].c), C.c_void_p)
+                    self.inst[j].world_to_local = (C.c_float * 12)(*[float(x) for x in np.asarray(i[1], np.float32).reshape(-1)[:12]])
         self.c = Bvh8(self.nodes.ctypes.data, self.leaf_idx.ctypes.data, int(root), self.prim_ids.ctypes.data,
-                      Mesh(self.pos.ctypes.data, self.idx.ctypes.data))
+                      Mesh(self.pos.ctypes.data, self.idx.ctypes.data), C.cast(self.inst, C.c_void_p) if self.inst is not None else None)
 
     @classmethod
     def from_host(cls, hb, mesh):
@@ -129,15 +145,17 @@ class OracleBvh8:
         n = rays.shape[1]
         rays = np.ascontiguousarray(rays, np.float32)
         t, u, v = (np.zeros(n, np.float32) for _ in range(3))
-        obj, hit = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        obj, hit, inst = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.full(n, MISS, np.uint32)
         cnt = Counters()
         if use_ref:
+            assert self.inst is None, "the simd-backed restatement has no instance leaves"
             ref().ref_bvh8_trace(C.byref(self.c), int(any_hit), tri_mode, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, u.ctypes.data, v.ctypes.data, hit.ctypes.data)
         else:
-            oracle().orc_bvh8_trace(C.byref(self.c), int(any_hit), tri_mode, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, u.ctypes.data, v.ctypes.data, hit.ctypes.data, C.byref(cnt), threads)
+            oracle().orc_bvh8_trace_inst(C.byref(self.c), int(any_hit), tri_mode, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, u.ctypes.data, v.ctypes.data,
+                                         hit.ctypes.data, inst.ctypes.data, C.byref(cnt), threads)
         if any_hit:
             return {"hit": hit, "counters": cnt.as_dict()}
-        return {"t": t, "obj": obj, "u": u, "v": v, "counters": cnt.as_dict()}
+        return {"t": t, "obj": obj, "u": u, "v": v, "inst": inst, "counters": cnt.as_dict()}
 
 
 class OracleScene:
@@ -163,18 +181,19 @@ class OracleScene:
         rays = np.ascontiguousarray(rays, np.float32)
         t, u, v = (np.zeros(n, np.float32) for _ in range(3))
         obj, leaf, hit, visits = (np.zeros(n, np.uint32) for _ in range(4))
+        inst = np.full(n, MISS, np.uint32)
         cnt = Counters()
         if use_ref:
             ref().ref_scene_trace(C.byref(self.c), int(any_hit), tri_mode, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, leaf.ctypes.data,
                                   u.ctypes.data, v.ctypes.data, hit.ctypes.data, visits.ctypes.data, C.byref(cnt))
         else:
-            oracle().orc_scene_trace(C.byref(self.c), int(any_hit), tri_mode, lanes, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, leaf.ctypes.data,
-                                     u.ctypes.data, v.ctypes.data, hit.ctypes.data, visits.ctypes.data, C.byref(cnt), threads)
+            oracle().orc_scene_trace_inst(C.byref(self.c), int(any_hit), tri_mode, lanes, rays.ctypes.data, n, t.ctypes.data, obj.ctypes.data, leaf.ctypes.data,
+                                          u.ctypes.data, v.ctypes.data, hit.ctypes.data, visits.ctypes.data, inst.ctypes.data, C.byref(cnt), threads)
         out = {"visits": visits, "counters": cnt.as_dict()}
         if any_hit:
             out["hit"] = hit
         else:
-            out.update({"t": t, "obj": obj, "leaf": leaf, "u": u, "v": v})
+            out.update({"t": t, "obj": obj, "leaf": leaf, "u": u, "v": v, "inst": inst})
         return out
 
 
@@ -212,6 +231,28 @@ def film_resolve(film: np.ndarray) -> np.ndarray:
 def scene_from_two_level(tl, mesh) -> OracleScene:
     """OracleScene for a pandora_amd.accel.TwoLevelScene (leaves in final slot order)."""
     leaf_bvhs = [OracleBvh8.from_host(tl.bvhs[int(src)], mesh) for src in tl.top.leaf_order]
+    if tl.dags is not None:
+        return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs, tl.dags.words, tl.dags.descs, [int(s) for s in tl.top.leaf_order])
+    return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs)
+
+
+def bvhs_from_instanced(tl):
+    """One OracleBvh8 per batching point of a pandora_amd.accel.InstancedTwoLevelScene (input order): leaf objects = the
+    point's triangles, then its instances."""
+    import pandora_amd as pa
+    protos = [OracleBvh8(b.nodes, b.leaf_idx, b.root, b.prim_ids, p, i) for b, (p, i) in zip(tl.proto_bvhs, tl.protos)]
+    out = []
+    for g, bvh in enumerate(tl.bvhs):
+        tris, insts = tl.group_tris[g], tl.group_insts[g]
+        prim_of_obj = np.concatenate([tris, np.zeros(insts.size, np.uint32)]).astype(np.uint32)
+        table = [None] * tris.size + [(protos[int(tl.inst_proto[k])], pa.accel.world_to_local_rows(tl.inst_matrix[k])) for k in insts]
+        out.append(OracleBvh8(bvh.nodes, bvh.leaf_idx, bvh.root, prim_of_obj, tl.pos, tl.idx, instances=table))
+    return out
+
+
+def scene_from_instanced(tl) -> OracleScene:
+    bvhs = bvhs_from_instanced(tl)
+    leaf_bvhs = [bvhs[int(src)] for src in tl.top.leaf_order]
     if tl.dags is not None:
         return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs, tl.dags.words, tl.dags.descs, [int(s) for s in tl.top.leaf_order])
     return OracleScene(tl.top.nodes, tl.top.root, leaf_bvhs)
