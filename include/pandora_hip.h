@@ -351,6 +351,47 @@ int pgpu_film_add(pgpu_ctx*, unsigned long long* film, size_t n_pixels, const ui
     const float* b, size_t n, void* stream);
 int pgpu_film_resolve(pgpu_ctx*, const unsigned long long* film, size_t n_pixels, float* rgb_out, void* stream);
 
+/* ------------------------------------------------------------------ the benchmark integrator's ray sources on the device
+ * (SURVEY.md 8f N4). The integrators stay host code in Pandora; once traversal runs at Grays/s, generating camera rays and
+ * bounce rays on the host and shipping them over PCIe dominates, so the three steps the benchmark integrator needs around
+ * the trace calls exist as kernels that read and write the same SoA arrays (all pointers device memory, work queued on `stream`):
+ *   pgpu_camera_rays    SamplerIntegrator::spawnNewPaths (integrators/sampler_integrator.cpp:131-163): sample index i = first + k,
+ *                       pixel = i / spp, rng = PcgRng(seed + i) (samplers/rng/pcg.cpp:23-39), camera sample = (pixel + rng.uniformFloat2())
+ *                       / resolution, PerspectiveCamera::generateRay (graphics_core/perspective_camera.cpp:37-47). `cam` holds the six
+ *                       member vectors PerspectiveCamera::updatePosition computes (:50-65). Fills rays and the path state.
+ *   pgpu_lambert_bounce PathIntegrator::randomBounce (integrators/path_integrator.cpp:139-158) for a Lambertian surface of constant
+ *                       albedo: hit record of the triangle test (geometric normal facing the ray, shapes/triangle_intersect.cpp:455-460),
+ *                       TriangleShape::fillSurfaceInteraction (hit point from the barycentrics, shapes/triangle_shading.cpp:11-21),
+ *                       BSDF frame (graphics_core/material.cpp:5-20), cosineSampleHemisphere (graphics_core/sampling.h:8-49),
+ *                       spawnRay with RAY_EPSILON offset (graphics_core/interaction.cpp:24-55), new PcgRng(rng.uniformU64()), weight update.
+ *                       Rays that missed (obj = PGPU_MISS) or whose sample has zero pdf become dead rays (tnear 1 > tfar 0: they miss
+ *                       everything). bvh_id = the single-level BVH the hits refer to, or PGPU_NO_BVH: hits->leaf names the batching
+ *                       point of the uploaded top level. Needs the vertices per leaf object on the device: pgpu_set_keep_shading(ctx, 1)
+ *                       BEFORE the BVHs are uploaded (36 bytes per leaf object; resident, non-instanced BVHs only).
+ *   pgpu_splat_misses   PathIntegrator::rayMiss with one constant infinite light (:113-125) + Sensor::addPixelContribution: every
+ *                       ray with obj = PGPU_MISS adds weight * sky to its pixel of the fixed-point film (pgpu_film_add's format).
+ * Arithmetic is binary32 in the reference's operation order; cos / sin of the disk mapping are the device's (<= 2 ulp from
+ * glibc's cosf / sinf, which the reference calls): bounce directions agree with the CPU restatement to 1e-6, everything else
+ * (camera rays, origins, rng streams, pixels, film) bit for bit. */
+typedef struct {
+    float lens_center[3], lens_du[3], lens_dv[3], screen_center[3], screen_du[3], screen_dv[3];
+} pgpu_camera;
+typedef struct {
+    float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar;
+} pgpu_rays_out;
+typedef struct {
+    unsigned long long *rng_state, *rng_inc; /* PcgRng m_state, m_inc */
+    uint32_t* pixel;                         /* y * width + x */
+    float *wr, *wg, *wb;                     /* BounceRayState::weight */
+} pgpu_paths;
+int pgpu_set_keep_shading(pgpu_ctx*, int on);
+int pgpu_camera_rays(pgpu_ctx*, const pgpu_camera* cam, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t first, size_t n,
+    const pgpu_rays_out* rays, const pgpu_paths* paths, void* stream);
+int pgpu_lambert_bounce(pgpu_ctx*, uint32_t bvh_id, const pgpu_rays* rays_in, const pgpu_hits* hits, size_t n, const float albedo[3],
+    const pgpu_rays_out* rays, const pgpu_paths* paths, void* stream);
+int pgpu_splat_misses(pgpu_ctx*, unsigned long long* film, size_t n_pixels, const uint32_t* obj, const pgpu_paths* paths, size_t n, const float sky[3],
+    void* stream);
+
 /* Diagnostics: device time of the traversal kernels of the last trace call on this context, measured
  * with HIP events on the stream they ran on (ms); enables/disables visit counters. */
 float pgpu_last_kernel_ms(const pgpu_ctx*);

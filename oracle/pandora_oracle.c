@@ -973,3 +973,188 @@ void orc_svdag_trace(const orc_svdag* d, int lanes, const float* rays, size_t n,
         out[i] = (unsigned char)orc_svdag_intersect(d, &r, lanes);
     }
 }
+
+/* ---------------------------------------------------------------- benchmark integrator pieces (N4) */
+
+/* samplers/rng/pcg.cpp:32-39 */
+static uint32_t pcg_u32(uint64_t* state, uint64_t inc)
+{
+    uint64_t old = *state;
+    *state = old * 0x5851F42D4C957F2DULL + inc;
+    uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+/* :23-30 */
+static void pcg_seed(uint64_t initseq, uint64_t* state, uint64_t* inc)
+{
+    *state = 0;
+    *inc = (initseq << 1u) | 1u;
+    pcg_u32(state, *inc);
+    *state += 0x853C49E6748FEA9BULL;
+    pcg_u32(state, *inc);
+}
+/* :58-61 */
+static float pcg_float(uint64_t* state, uint64_t inc)
+{
+    float f = (float)pcg_u32(state, inc) * 0x1p-32f;
+    float lim = 1.0f - FLT_EPSILON;
+    return lim < f ? lim : f; /* std::min(lim, f) */
+}
+
+static void normalize3(float v[3])
+{
+    /* glm::normalize = v * inversesqrt(dot(v, v)), inversesqrt(x) = 1 / sqrt(x) */
+    float inv = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    v[0] *= inv;
+    v[1] *= inv;
+    v[2] *= inv;
+}
+
+void orc_camera_rays(const orc_camera* cam, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t first, size_t n,
+    float* rays, const orc_paths* paths)
+{
+    const float resx = (float)width, resy = (float)height;
+    for (size_t k = 0; k < n; k++) {
+        const uint64_t i = first + k; /* sampler_integrator.cpp:145-160 */
+        const uint64_t pixelIndex = i / spp;
+        const uint32_t x = (uint32_t)(pixelIndex % width), y = (uint32_t)(pixelIndex / width);
+        uint64_t st, inc;
+        pcg_seed(seed + i, &st, &inc);
+        const float r0 = pcg_float(&st, inc), r1 = pcg_float(&st, inc);
+        const float sx = ((float)x + r0) / resx, sy = ((float)y + r1) / resy;
+        const float cx = sx - 0.5f, cy = sy - 0.5f; /* perspective_camera.cpp:39 */
+        float o[3], d[3];
+        for (int a = 0; a < 3; a++) {
+            o[a] = (cam->lens_center[a] + cx * cam->lens_du[a]) + cy * cam->lens_dv[a];
+            const float sc = (cam->screen_center[a] + cx * cam->screen_du[a]) + cy * cam->screen_dv[a];
+            d[a] = sc - o[a];
+        }
+        normalize3(d);
+        for (int a = 0; a < 3; a++) {
+            rays[(size_t)a * n + k] = o[a];
+            rays[(size_t)(3 + a) * n + k] = d[a];
+        }
+        rays[6 * n + k] = 0.0f;
+        rays[7 * n + k] = FLT_MAX;
+        if (paths) {
+            paths->rng_state[k] = st;
+            paths->rng_inc[k] = inc;
+            paths->pixel[k] = y * width + x;
+            paths->wr[k] = paths->wg[k] = paths->wb[k] = 1.0f;
+        }
+        (void)height;
+    }
+}
+
+static void dead_ray(float* rays, size_t n, size_t k)
+{
+    for (int a = 0; a < 6; a++)
+        rays[(size_t)a * n + k] = a == 3 ? 1.0f : 0.0f;
+    rays[6 * n + k] = 1.0f;
+    rays[7 * n + k] = 0.0f;
+}
+
+void orc_lambert_bounce(const orc_bvh8* b1, const orc_scene* s, const float* rays_in, const float* t, const uint32_t* obj, const uint32_t* leaf,
+    const float* u, const float* v, size_t n, const float albedo[3], float* rays, const orc_paths* paths)
+{
+    (void)t;
+    for (size_t k = 0; k < n; k++) {
+        if (obj[k] == ORC_MISS) {
+            dead_ray(rays, n, k);
+            continue;
+        }
+        const orc_bvh8* b = b1 ? b1 : &s->leaves[leaf[k]].bvh;
+        const uint32_t prim = b->obj_prim ? b->obj_prim[obj[k]] : obj[k];
+        const float *p0 = tri_vertex(&b->mesh, prim, 0), *p1 = tri_vertex(&b->mesh, prim, 1), *p2 = tri_vertex(&b->mesh, prim, 2);
+        const float dir[3] = { rays_in[3 * n + k], rays_in[4 * n + k], rays_in[5 * n + k] };
+        /* triangle_intersect.cpp:458-460 */
+        float e1[3], e2[3], ng[3];
+        for (int a = 0; a < 3; a++) {
+            e1[a] = p1[a] - p0[a];
+            e2[a] = p2[a] - p0[a];
+        }
+        cross3(e1, e2, ng);
+        normalize3(ng);
+        if (((ng[0] * -dir[0] + ng[1] * -dir[1]) + ng[2] * -dir[2]) < 0.0f)
+            for (int a = 0; a < 3; a++)
+                ng[a] = -ng[a];
+        /* triangle_shading.cpp:14-21 */
+        const float b0 = 1.0f - u[k] - v[k], bb1 = u[k], bb2 = v[k];
+        float pos[3];
+        for (int a = 0; a < 3; a++)
+            pos[a] = (b0 * p0[a] + bb1 * p1[a]) + bb2 * p2[a];
+        /* material.cpp:5-20 */
+        const float helper[3] = { ng[0] > 0.5f ? 0.0f : 1.0f, ng[0] > 0.5f ? 1.0f : 0.0f, 0.0f };
+        float ss[3], ts[3];
+        cross3(ng, helper, ss);
+        normalize3(ss);
+        cross3(ng, ss, ts);
+        normalize3(ts);
+        /* path_integrator.cpp:142 -> material.cpp:85-100 -> LambertianReflection::sampleF -> sampling.h:8-49 */
+        uint64_t st = paths->rng_state[k];
+        const uint64_t inc = paths->rng_inc[k];
+        const float r0 = pcg_float(&st, inc), r1 = pcg_float(&st, inc);
+        const float ox = 2.0f * r0 - 1.0f, oy = 2.0f * r1 - 1.0f;
+        float dx = 0.0f, dy = 0.0f;
+        if (!(ox == 0.0f && oy == 0.0f)) {
+            const float pi = 3.14159265358979323846264338327950288f;
+            float theta, r;
+            if (fabsf(ox) > fabsf(oy)) {
+                r = ox;
+                theta = pi / 4.0f * (oy / ox);
+            } else {
+                r = oy;
+                theta = pi / 2.0f - pi / 4.0f * (ox / oy);
+            }
+            dx = r * cosf(theta);
+            dy = r * sinf(theta);
+        }
+        const float zz = 1.0f - dx * dx - dy * dy;
+        float wl[3] = { dx, dy, sqrtf(0.0f > zz ? 0.0f : zz) }; /* std::max(0.0f, zz) */
+        /* wo = -dir faces the flipped normal, so wo.z = dot(wo, ns) >= 0: LambertianReflection keeps wi.z unless wo.z < 0 */
+        const float woz = (-dir[0] * ng[0] + -dir[1] * ng[1]) + -dir[2] * ng[2];
+        if (woz < 0.0f)
+            wl[2] = -wl[2];
+        float wi[3];
+        for (int a = 0; a < 3; a++)
+            wi[a] = (ss[a] * wl[0] + ts[a] * wl[1]) + ng[a] * wl[2]; /* material.cpp:41-47 */
+        /* pdf = |wi.z| / pi when wo, wi lie in one hemisphere, else 0 -> no bounce (material.cpp:93-94, path_integrator.cpp:142) */
+        const float inv_pi = 0.318309886183790671537767526745028724f;
+        const float pdf = (woz * wl[2] > 0.0f) ? fabsf(wl[2]) * inv_pi : 0.0f;
+        /* rayState.rng = PcgRng(rng.uniformU64()) (:151) -- drawn whether or not the bounce survives keeps the stream position simple */
+        const uint64_t left = pcg_u32(&st, inc), right = pcg_u32(&st, inc);
+        uint64_t nst, ninc;
+        pcg_seed((left << 32) | right, &nst, &ninc);
+        paths->rng_state[k] = nst;
+        paths->rng_inc[k] = ninc;
+        if (!(pdf > 0.0f) || (albedo[0] == 0.0f && albedo[1] == 0.0f && albedo[2] == 0.0f)) {
+            dead_ray(rays, n, k);
+            continue;
+        }
+        /* weight = prev * f * absDot(wi, ns) / pdf with f = albedo / pi (:152) */
+        const float adot = fabsf((wi[0] * ng[0] + wi[1] * ng[1]) + wi[2] * ng[2]);
+        paths->wr[k] = paths->wr[k] * (albedo[0] * inv_pi) * adot / pdf;
+        paths->wg[k] = paths->wg[k] * (albedo[1] * inv_pi) * adot / pdf;
+        paths->wb[k] = paths->wb[k] * (albedo[2] * inv_pi) * adot / pdf;
+        /* interaction.cpp:39-55: origin offset along the normal on the side the ray leaves from */
+        const float side = ((ng[0] * wi[0] + ng[1] * wi[1]) + ng[2] * wi[2]) > 0.0f ? 1.0f : -1.0f;
+        for (int a = 0; a < 3; a++) {
+            rays[(size_t)a * n + k] = side > 0.0f ? pos[a] + ng[a] * 0.000005f : pos[a] - ng[a] * 0.000005f;
+            rays[(size_t)(3 + a) * n + k] = wi[a];
+        }
+        rays[6 * n + k] = 0.0f;
+        rays[7 * n + k] = FLT_MAX;
+    }
+}
+
+void orc_splat_misses(uint64_t* film, size_t n_pixels, const uint32_t* obj, const orc_paths* paths, size_t n, const float sky[3])
+{
+    for (size_t k = 0; k < n; k++) {
+        if (obj[k] != ORC_MISS)
+            continue;
+        /* path_integrator.cpp:113-125: weight * Le; sensor.cpp:36-49 */
+        const float r = paths->wr[k] * sky[0], g = paths->wg[k] * sky[1], b = paths->wb[k] * sky[2];
+        orc_film_add(film, n_pixels, &paths->pixel[k], &r, &g, &b, 1);
+    }
+}

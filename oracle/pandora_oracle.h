@@ -184,6 +184,30 @@ void orc_svdag_trace(const orc_svdag* d, int lanes, const float* rays, size_t n,
 void orc_film_add(uint64_t* film, size_t n_pixels, const uint32_t* pixel, const float* r, const float* g, const float* b, size_t n);
 void orc_film_resolve(const uint64_t* film, size_t n_pixels, float* rgb_out); /* sensor.cpp:96-99 */
 
+/* ---- the benchmark integrator's ray sources and film splat, restated in binary32:
+ * PcgRng (samplers/rng/pcg.cpp:23-39,58-61), SamplerIntegrator::spawnNewPaths (integrators/sampler_integrator.cpp:131-163),
+ * PerspectiveCamera::generateRay (graphics_core/perspective_camera.cpp:37-47), the hit record of the triangle test
+ * (shapes/triangle_intersect.cpp:455-460), TriangleShape::fillSurfaceInteraction (shapes/triangle_shading.cpp:11-42, meshes
+ * without vertex normals), BSDF::BSDF / sampleF / localToWorld (graphics_core/material.cpp:5-47,85-100) with one
+ * LambertianReflection (cosineSampleHemisphere, graphics_core/sampling.h:8-49), PathIntegrator::randomBounce
+ * (integrators/path_integrator.cpp:139-158), Interaction::spawnRay (graphics_core/interaction.cpp:24-27,39-55),
+ * PathIntegrator::rayMiss with one constant infinite light (:113-125). cos / sin are libm's cosf / sinf. */
+typedef struct {
+    float lens_center[3], lens_du[3], lens_dv[3], screen_center[3], screen_du[3], screen_dv[3]; /* members after updatePosition (:50-65) */
+} orc_camera;
+typedef struct {
+    uint64_t *rng_state, *rng_inc; /* PcgRng m_state, m_inc */
+    uint32_t* pixel;               /* y * width + x */
+    float *wr, *wg, *wb;           /* BounceRayState::weight */
+} orc_paths;
+void orc_camera_rays(const orc_camera* cam, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t first, size_t n,
+    float* rays_out /* [8][n] */, const orc_paths* paths);
+/* One Lambert bounce for every ray that hit (obj != ORC_MISS); the others (and failed samples) become dead rays (tnear 1, tfar 0).
+ * Single level: b != NULL, leaf ignored; two level: s != NULL, leaf = batching point of the hit. */
+void orc_lambert_bounce(const orc_bvh8* b, const orc_scene* s, const float* rays_in, const float* t, const uint32_t* obj, const uint32_t* leaf,
+    const float* u, const float* v, size_t n, const float albedo[3], float* rays_out, const orc_paths* paths);
+void orc_splat_misses(uint64_t* film, size_t n_pixels, const uint32_t* obj, const orc_paths* paths, size_t n, const float sky[3]);
+
 #ifdef __cplusplus
 }
 #endif

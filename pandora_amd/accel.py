@@ -63,6 +63,27 @@ def build_bvh8(pos: np.ndarray, idx: np.ndarray, prim_ids: np.ndarray | None = N
         L.pgpu_host_bvh8_free(h)
 
 
+def make_camera(eye, look_at, up, fov_x_deg: float, aspect: float, lens_radius: float = 0.0, focal_distance: float = 1.0) -> "capi.Camera":
+    """PerspectiveCamera::updatePosition (graphics_core/perspective_camera.cpp:50-65) in binary32 for a camera whose transform has
+    the columns (right, up, forward, eye). The result is what pgpu_camera_rays / the oracle's orc_camera_rays take."""
+    f32 = np.float32
+    eye, look_at, up = (np.asarray(a, np.float64) for a in (eye, look_at, up))
+    fwd = look_at - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    upv = np.cross(right, fwd)
+    t0, t1, t2, t3 = (v.astype(f32) for v in (right, upv, fwd, eye))
+    lr, fd, ar = f32(lens_radius), f32(focal_distance), f32(aspect)
+    dist = f32(0.5) / f32(np.tan(f32(np.radians(f32(fov_x_deg) / f32(2.0)))))
+    cam = capi.Camera()
+    vals = {"lens_center": t3, "lens_du": lr * t0, "lens_dv": lr * t1 / ar, "screen_center": t3 + fd * t2,
+            "screen_du": -fd / dist * t0, "screen_dv": -fd / dist * t1 / ar}
+    for k, v in vals.items():
+        setattr(cam, k, (C.c_float * 3)(*[float(f32(x)) for x in v]))
+    return cam
+
+
 def build_bvh8_boxes(bounds: np.ndarray, alone: np.ndarray | None = None, max_leaf: int = 4) -> HostBvh8:
     """BVH8 over arbitrary leaf objects given by their bounds [n, 6]; object j is leaf object j. alone[j] != 0 gives
     object j a leaf of its own (instances)."""
@@ -522,6 +543,46 @@ class Context:
     def film_allreduce(self, film, stream: int = 0):
         """Sums the int64 fixed-point films of all ranks in place (pgpu_film_allreduce)."""
         _check(self._L.pgpu_film_allreduce(self._h, capi.ptr(film), int(film.numel() // 3), stream), self._h)
+
+    # -- the benchmark integrator's ray sources on the device (pgpu_camera_rays / pgpu_lambert_bounce / pgpu_splat_misses)
+    def set_keep_shading(self, on: bool = True):
+        """Uploads that follow also keep the vertices per leaf object on the device (what lambert_bounce reads)."""
+        _check(self._L.pgpu_set_keep_shading(self._h, int(on)), self._h)
+
+    @staticmethod
+    def _paths_struct(paths: dict):
+        return capi.Paths(*[capi.ptr(paths[k]) for k in ("rng_state", "rng_inc", "pixel", "wr", "wg", "wb")])
+
+    def camera_rays(self, cam, width: int, height: int, spp: int, seed: int, first: int, n: int, device, stream: int = 0):
+        """-> (rays [8, n] float32 device tensor, path state dict of device tensors)."""
+        import torch
+        rays = torch.empty((8, n), dtype=torch.float32, device=device)
+        paths = {"rng_state": torch.empty(n, dtype=torch.int64, device=device), "rng_inc": torch.empty(n, dtype=torch.int64, device=device),
+                 "pixel": torch.empty(n, dtype=torch.int32, device=device)}
+        paths.update({k: torch.empty(n, dtype=torch.float32, device=device) for k in ("wr", "wg", "wb")})
+        r, _ = self._rays_struct(rays)
+        p = self._paths_struct(paths)
+        _check(self._L.pgpu_camera_rays(self._h, C.byref(cam), width, height, spp, seed, first, n, C.byref(r), C.byref(p), stream), self._h)
+        return rays, paths
+
+    def lambert_bounce(self, bvh_id, rays, hits: dict, albedo, paths: dict, stream: int = 0):
+        """One Lambert bounce per hit (bvh_id None: two-level hits, hits["leaf"] names the batching point). Updates `paths`
+        in place and returns the bounce rays [8, n] (dead rays where there is no bounce)."""
+        import torch
+        n = int(rays.shape[1])
+        out = torch.empty_like(rays)
+        r_in, _ = self._rays_struct(rays)
+        r_out, _ = self._rays_struct(out)
+        h = capi.Hits(capi.ptr(hits["t"]), capi.ptr(hits["obj"]), capi.ptr(hits.get("leaf")), capi.ptr(hits["u"]), capi.ptr(hits["v"]), 0)
+        p = self._paths_struct(paths)
+        alb = (C.c_float * 3)(*[float(x) for x in albedo])
+        _check(self._L.pgpu_lambert_bounce(self._h, capi.NO_BVH if bvh_id is None else bvh_id, C.byref(r_in), C.byref(h), n, alb, C.byref(r_out), C.byref(p), stream), self._h)
+        return out
+
+    def splat_misses(self, film, obj, paths: dict, sky, stream: int = 0):
+        p = self._paths_struct(paths)
+        s = (C.c_float * 3)(*[float(x) for x in sky])
+        _check(self._L.pgpu_splat_misses(self._h, capi.ptr(film), int(film.numel() // 3), capi.ptr(obj), C.byref(p), int(obj.numel()), s, stream), self._h)
 
     def film_add(self, film, pixel, r, g, b, stream: int = 0):
         """Sensor::addPixelContribution over a batch (sensor.cpp:36-49). film: int64 device tensor [n_pixels, 3] (40.24

@@ -48,6 +48,15 @@ class Transport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("allgather_u32", ALLGATHER_FN), ("exchange", EXCHANGE_FN), ("allreduce_u64", ALLREDUCE_FN)]
 
 
+class Camera(C.Structure):
+    """pgpu_camera: PerspectiveCamera's member vectors after updatePosition (perspective_camera.cpp:50-65)."""
+    _fields_ = [(n, C.c_float * 3) for n in ("lens_center", "lens_du", "lens_dv", "screen_center", "screen_du", "screen_dv")]
+
+
+class Paths(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rng_state", "rng_inc", "pixel", "wr", "wg", "wb")]
+
+
 class LeafObj(C.Structure):
     _fields_ = [("mesh", C.c_uint32), ("prim", C.c_uint32)]
 
@@ -131,6 +140,10 @@ SYMBOLS = {
     "pgpu_set_leaf_owners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "pgpu_trace_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits), C.c_void_p, C.POINTER(Counters), C.c_void_p]),
     "pgpu_film_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pgpu_set_keep_shading": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgpu_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),
+    "pgpu_lambert_bounce": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Rays), C.POINTER(Hits), C.c_size_t, C.POINTER(C.c_float), C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),
+    "pgpu_splat_misses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Paths), C.c_size_t, C.POINTER(C.c_float), C.c_void_p]),
     "pgpu_film_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgpu_film_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

@@ -302,6 +302,14 @@ int pgpu_set_stats(pgpu_ctx* c, int enabled)
     return PGPU_OK;
 }
 
+int pgpu_set_keep_shading(pgpu_ctx* c, int on)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    c->keepShading = on != 0;
+    return PGPU_OK;
+}
+
 int pgpu_set_tuning(pgpu_ctx* c, int blocks_per_cu, int chunk)
 {
     if (!c || blocks_per_cu < 0 || blocks_per_cu > 8 || (chunk != 0 && chunk < 8) || chunk > 65536)
@@ -357,7 +365,7 @@ int pgpu_upload_mesh(pgpu_ctx* c, const float* positions, size_t n_vertices, con
 // Validation shared by pgpu_upload_bvh8 and pgpu_stage_bvh8 + the gather of every leaf slot's triangle (see Bvh8Dev in kernels.h).
 static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, std::vector<float>& tris,
-    std::vector<InstDev>& inst, Bvh8Dev& d)
+    std::vector<InstDev>& inst, Bvh8Dev& d, std::vector<float>* shade = nullptr)
 {
     auto bad = [&](int code, const char* what) {
         c->err = std::string(who) + ": " + what;
@@ -374,6 +382,8 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
     if (7 * depth + 8 > 96) // the 96-entry traversal stack of wive_bvh8_impl.h:74-75
         return bad(PGPU_ERR_DEPTH, "more than 12 nested inner nodes");
     tris.assign((n_indices + 1) * 12, 0.0f); // (one zero record of padding: the pair kernel reads records two at a time)
+    if (shade)
+        shade->assign(n_objs * 9, 0.0f);
     std::vector<uint8_t> instSlot(n_indices, 0);
     uint32_t childDepth = 0;
     inst.clear();
@@ -419,6 +429,8 @@ static int prepareBvh8(pgpu_ctx* c, const char* who, const void* nodes256, size_
             t[4 * k + 0] = p[0];
             t[4 * k + 1] = p[1];
             t[4 * k + 2] = p[2];
+            if (shade)
+                std::memcpy(&(*shade)[size_t(obj) * 9 + size_t(k) * 3], p, 12);
         }
         std::memcpy(&t[3], &obj, 4);
     }
@@ -470,14 +482,22 @@ int pgpu_upload_bvh8_instanced(pgpu_ctx* c, const void* nodes256, size_t n_nodes
     if (!c || !bvh_id || (n_instances && !instances))
         return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<float> tris;
+    std::vector<float> tris, shade;
     std::vector<InstDev> inst;
     Bvh8Dev d {};
-    int rc = prepareBvh8(c, "pgpu_upload_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, instances, n_instances, tris, inst, d);
+    int rc = prepareBvh8(c, "pgpu_upload_bvh8", nodes256, n_nodes, leaf_indices, n_indices, root_handle, objs, n_objs, instances, n_instances, tris, inst, d,
+        c->keepShading ? &shade : nullptr);
     if (rc != PGPU_OK)
         return rc;
     unsigned char* devNodes = nullptr;
     float* devTris = nullptr;
+    if (c->keepShading) {
+        float* devShade = nullptr;
+        rc = uploadArray(c, shade.data(), shade.size(), &devShade);
+        if (rc != PGPU_OK)
+            return rc;
+        d.shade = devShade;
+    }
     if (!inst.empty()) {
         InstDev* devInst = nullptr;
         rc = uploadArray(c, inst.data(), inst.size(), &devInst);

@@ -47,6 +47,7 @@ struct pgpu_ctx {
     DeviceBuffer spill;      // global overflow of the per-ray stacks
     unsigned char* staticScratch = nullptr; // this device's copy of the static scratch array of noalloc.hip (resolved at pgpu_init)
 
+    bool keepShading = false;  // uploads also keep the vertices per leaf object on the device (pgpu_set_keep_shading)
     bool hasInstances = false; // some BVH holds instance leaves: the bottom-level launches use the kernel variant that follows them
     std::vector<HostMesh> meshes;
     std::vector<pandora_hip::Bvh8Dev> bvhs; // host mirror of the device table

@@ -27,6 +27,8 @@ struct Bvh8Dev {
     uint32_t needs_exact; // some child box is unordered or non-finite: always use the x86-exact slab test
     uint32_t n_inst;      // entries of `inst`
     const unsigned char* inst; // InstDev table of the instance leaves (nullptr: every leaf object is a triangle)
+    const float* shade;        // 9 floats per leaf object: the triangle's vertices, for the benchmark integrator's bounce kernel
+                               // (nullptr unless pgpu_set_keep_shading was on at upload)
 };
 
 // One instance (OfflineBVHLeaf::Instance, offline_bvh_cache.h:18-39): the BVH it shows and the world-to-local transform

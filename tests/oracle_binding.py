@@ -228,6 +228,63 @@ def film_resolve(film: np.ndarray) -> np.ndarray:
     return out
 
 
+# ---------------------------------------------------------------------------- benchmark integrator pieces (N4)
+class OrcCamera(C.Structure):
+    _fields_ = [(n, C.c_float * 3) for n in ("lens_center", "lens_du", "lens_dv", "screen_center", "screen_du", "screen_dv")]
+
+
+class OrcPaths(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rng_state", "rng_inc", "pixel", "wr", "wg", "wb")]
+
+
+def new_paths(n):
+    p = {"rng_state": np.zeros(n, np.uint64), "rng_inc": np.zeros(n, np.uint64), "pixel": np.zeros(n, np.uint32)}
+    p.update({k: np.zeros(n, np.float32) for k in ("wr", "wg", "wb")})
+    return p
+
+
+def _paths_struct(p):
+    return OrcPaths(*[p[k].ctypes.data for k in ("rng_state", "rng_inc", "pixel", "wr", "wg", "wb")])
+
+
+def camera_rays(cam, width, height, spp, seed, first, n):
+    """orc_camera_rays; `cam` = a pandora_amd.capi.Camera (same layout)."""
+    rays = np.zeros((8, n), np.float32)
+    paths = new_paths(n)
+    oc = OrcCamera.from_buffer_copy(bytes(cam))
+    f = oracle().orc_camera_rays
+    f.argtypes = [C.POINTER(OrcCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.POINTER(OrcPaths)]
+    f.restype = None
+    ps = _paths_struct(paths)
+    f(C.byref(oc), width, height, spp, seed, first, n, rays.ctypes.data, C.byref(ps))
+    return rays, paths
+
+
+def lambert_bounce(bvh: "OracleBvh8 | None", scene: "OracleScene | None", rays, hits: dict, albedo, paths: dict):
+    """orc_lambert_bounce: updates `paths` in place, returns the bounce rays."""
+    n = rays.shape[1]
+    rays = np.ascontiguousarray(rays, np.float32)
+    out = np.zeros((8, n), np.float32)
+    f = oracle().orc_lambert_bounce
+    f.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 6 + [C.c_size_t, C.POINTER(C.c_float), C.c_void_p, C.POINTER(OrcPaths)]
+    f.restype = None
+    g = lambda k, dt: np.ascontiguousarray(hits[k], dt) if k in hits else np.zeros(n, dt)
+    t, obj, leaf, u, v = g("t", np.float32), g("obj", np.uint32), g("leaf", np.uint32), g("u", np.float32), g("v", np.float32)
+    ps = _paths_struct(paths)
+    f(C.byref(bvh.c) if bvh is not None else None, C.byref(scene.c) if scene is not None else None, rays.ctypes.data, t.ctypes.data, obj.ctypes.data,
+      leaf.ctypes.data, u.ctypes.data, v.ctypes.data, n, (C.c_float * 3)(*[float(x) for x in albedo]), out.ctypes.data, C.byref(ps))
+    return out
+
+
+def splat_misses(film: np.ndarray, obj, paths: dict, sky):
+    f = oracle().orc_splat_misses
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(OrcPaths), C.c_size_t, C.POINTER(C.c_float)]
+    f.restype = None
+    obj = np.ascontiguousarray(obj, np.uint32)
+    ps = _paths_struct(paths)
+    f(film.ctypes.data, film.size // 3, obj.ctypes.data, C.byref(ps), obj.size, (C.c_float * 3)(*[float(x) for x in sky]))
+
+
 def scene_from_two_level(tl, mesh) -> OracleScene:
     """OracleScene for a pandora_amd.accel.TwoLevelScene (leaves in final slot order)."""
     leaf_bvhs = [OracleBvh8.from_host(tl.bvhs[int(src)], mesh) for src in tl.top.leaf_order]
