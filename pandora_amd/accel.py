@@ -65,7 +65,7 @@ def build_bvh8(pos: np.ndarray, idx: np.ndarray, prim_ids: np.ndarray | None = N
 
 def make_camera(eye, look_at, up, fov_x_deg: float, aspect: float, lens_radius: float = 0.0, focal_distance: float = 1.0) -> "capi.Camera":
     """PerspectiveCamera::updatePosition (graphics_core/perspective_camera.cpp:50-65) in binary32 for a camera whose transform has
-    the columns (right, up, forward, eye). The result is what pgpu_camera_rays / the oracle's orc_camera_rays take."""
+    the columns (right, up, forward, eye). The result is what pgpu_camera_rays takes."""
     f32 = np.float32
     eye, look_at, up = (np.asarray(a, np.float64) for a in (eye, look_at, up))
     fwd = look_at - eye
