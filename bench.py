@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=0, help="rays of the batch the CPU port traces (and the GPU result is compared on); 0 = automatic: the whole batch for the single-level config (~20 s of CPU work), 2^21 rays for two-level")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--city-blocks", type=int, default=24, help="two-level / sharded scene: city blocks per side (24 -> 11.4 M triangles)")
+    ap.add_argument("--svdag-defer", type=int, default=0, help="two-level: SVDAG casts of passes with at least this many rays run as a kernel of their own (pgpu_set_svdag_defer; 0 = inside the episode, the default)")
     ap.add_argument("--svdag", type=int, default=64, help="two-level / sharded scene: SVDAG resolution (0 = no proxy geometry, svdagRes 0 in the reference)")
     ap.add_argument("--sharded-side", type=int, default=2048, help="N > 1: primary image side per rank of the sharded record")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded record")
@@ -191,6 +192,8 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
     """configs[2]: PauseableBVH4 + 64^3 SVDAGs + per-point BVH8 on one GPU (the whole round loop is the step)."""
     mesh, tl = city_scene(pa, args.city_blocks, svdag=args.svdag)
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+    if args.svdag_defer:
+        ctx.set_svdag_defer(args.svdag_defer, 2)
     stream = torch.cuda.current_stream().cuda_stream
     prim = city_camera(pa, args.city_blocks, args.side, 891379 + 7919 * rank)
     first, _ = ctx.trace(torch.from_numpy(prim).to(dev), stream=stream)

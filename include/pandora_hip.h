@@ -176,6 +176,13 @@ int pgpu_set_leaf_cache(pgpu_ctx*, size_t bytes);
 
 /* Shared SVDAG array + one descriptor per DAG (SparseVoxelDAG members, sparse_voxel_dag.h:70-78). */
 int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags);
+/* Where pgpu_trace runs the SVDAG casts (same results either way, bit for bit; no counterpart in the reference, whose cast is
+ * a call inside PauseableBVH4::intersectT, pauseable_bvh4.h:376-396). min_rays = 0 (the default): inside the top-level
+ * episode kernel. min_rays > 0: passes of at least that many rays stop at every batching point that has a DAG, the cast
+ * requests are sorted by point and cast by a kernel that stages the point's DAG in LDS, `passes` (1..8) times per round
+ * before the episode kernel finishes the remainder. Measured slower on the benchmark scene; kept
+ * selectable for scenes with deeper DAGs or higher cull rates. */
+int pgpu_set_svdag_defer(pgpu_ctx*, uint32_t min_rays, uint32_t passes);
 
 /* Top-level PauseableBVH4 (m_bvhNodes, m_leafs, m_rootHandle; pauseable_bvh4.h:100-103). Leaf k is a
  * batching point: its bottom-level BVH and its SVDAG (PGPU_NO_SVDAG = none, i.e. svdagRes 0). */

@@ -544,6 +544,11 @@ class Context:
         """Sums the int64 fixed-point films of all ranks in place (pgpu_film_allreduce)."""
         _check(self._L.pgpu_film_allreduce(self._h, capi.ptr(film), int(film.numel() // 3), stream), self._h)
 
+    def set_svdag_defer(self, min_rays: int = 0, passes: int = 2):
+        """Where trace() runs the SVDAG casts: 0 = inside the top-level episode (default); > 0 = passes of at least that many
+        rays cast in a kernel of their own, `passes` times per round (pgpu_set_svdag_defer). Same results bit for bit."""
+        _check(self._L.pgpu_set_svdag_defer(self._h, int(min_rays), int(passes)), self._h)
+
     # -- the benchmark integrator's ray sources on the device (pgpu_camera_rays / pgpu_lambert_bounce / pgpu_splat_misses)
     def set_keep_shading(self, on: bool = True):
         """Uploads that follow also keep the vertices per leaf object on the device (what lambert_bounce reads)."""

@@ -242,7 +242,7 @@ __device__ __forceinline__ void ldsStoreU4(lds_u8* p, uint32_t x, uint32_t y, ui
 // keeps its meaning) and the nested traversal runs on the same per-ray stack above a floor (spBase); when the stack is back at
 // the floor the ray is reloaded and the outer traversal goes on with whatever tfar the instance left. One level of nesting.
 template <bool ANY, int TRI, bool STATS, bool INST>
-__device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs& a)
+__device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by value: through a reference the compiler keeps the arguments in SGPRs it then has to spill)
 {
     extern __shared__ __align__(16) unsigned char ldsGeneric[];
     lds_u8* const lds = (lds_u8*)ldsGeneric;

@@ -76,6 +76,7 @@ struct SvdagDev {
     float bmin[3];
     float invExtent;
     uint32_t levels; // height of this DAG (bounds the loop trips of a cast that makes progress)
+    uint32_t img_offset, img_words; // this DAG's private image inside TopDev::dagImages (see there)
 };
 struct TopLeafDev {
     uint32_t bvh;
@@ -88,8 +89,18 @@ struct TopDev {
     const SvdagDev* dags;
     uint32_t root, n_nodes, n_leaves, n_dags;
     uint32_t dag_levels; // height of the tallest SVDAG = entries of the cast's saved-parent stack
-    uint32_t pad;
+    uint32_t img_max_words; // the largest image (sizes the cast kernel's LDS)
+    // Per-DAG images for the cast kernel, which stages the DAG of the batching point it works on in LDS: the nodes of ONE
+    // DAG, breadth first from its root (index 0), in the array's own format (descriptor word + one offset per inner child)
+    // but with offsets local to the image. The shared array hash-conses subtrees across DAGs, so one DAG's nodes are
+    // scattered over it; the image is contiguous and at most kDagImageMaxWords long -- nodes that do not fit stay in the
+    // shared array and are referred to as 0x80000000 | offset there.
+    const uint32_t* dagImages;
 };
+constexpr uint32_t kDagImageMaxWords = 6144; // 24 KiB
+constexpr uint32_t kDagGlobalFlag = 0x80000000u;
+constexpr uint32_t kCastRequestFlag = 0x80000000u; // parked_leaf value of a ray waiting for its cast: flag | batching point
+constexpr uint32_t kCastCulled = 0xFFFFFFFEu;      // parked_leaf value of a ray whose cast missed: it goes on with its traversal
 
 struct TopTraceArgs {
     TopDev top;
@@ -109,14 +120,46 @@ struct TopTraceArgs {
     uint32_t may_park; // 0: a ray that reaches a batching point leaves instead of pausing (it has paused n_leaves times)
     uint32_t* leaf_count;
     unsigned long long* counters; // [0] svdag tests, [1] svdag culled
+    // Deferred casts (launchTopTraverse with defer = true, then scan + bin of the requests + launchSvdagCast): the episode
+    // stops at a batching point that has proxy geometry instead of casting through it -- token saved, parked_leaf = the point
+    // with kCastRequestFlag, one count per point in req_leaf_count. only_culled: advance only the positions whose cast missed
+    // in the previous pass (parked_leaf == kCastCulled); the others are left as they are.
+    uint32_t only_culled;
+    uint32_t* req_leaf_count;
+};
+
+// The SVDAG casts of one pass as a kernel of their own. Requests (positions of the round's list) arrive sorted by batching
+// point; a block takes a contiguous slice of them and, for every batching point in its slice, stages that point's DAG image in
+// LDS and runs the casts from there -- every lane takes the next request of the run when its cast is done, so a wave does
+// uniform work and no cast touches L1 / L2 (inside a top-level episode every trip of every lane reads 4 bytes of some DAG
+// somewhere: a 64-byte line per lane and trip, which is what bounds the episode kernel). A hit leaves the ray parked
+// (parked_leaf = the point, counted in leaf_count, visits + 1); a miss sets parked_leaf = kCastCulled.
+struct CastArgs {
+    TopDev top;
+    const uint32_t* active; // position -> ray id (nullptr: identity)
+    const float *ox, *oy, *oz, *dx, *dy, *dz;
+    uint32_t* parked_leaf;
+    uint32_t* visits; // may be nullptr
+    const uint32_t* req_list;  // positions, sorted by batching point
+    const uint32_t* req_start; // per batching point: first request
+    const uint32_t* req_count; // per batching point: number of requests
+    const uint32_t* unit_start; // per batching point: first work unit (svdagPlanKernel)
+    uint32_t* plan;             // [0] work units of the pass, [1] the unit cursor
+    uint32_t* leaf_count;
+    unsigned long long* counters; // [0] svdag tests, [1] svdag culled
 };
 
 bool topNodesFitLds(uint32_t nNodes);
-hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream);
+hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream, bool defer = false);
+hipError_t launchSvdagCast(const CastArgs& a, uint32_t blocks, hipStream_t stream);
+hipError_t launchSvdagPlan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t* unitStart, uint32_t n, uint32_t* plan, hipStream_t stream);
+size_t svdagCastLdsBytes(const TopDev& top);
 size_t topTraverseLdsBytes(const TopDev& top);
 hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream);
+// requests = true: bins the positions whose parked_leaf carries kCastRequestFlag (by the batching point under the flag)
 hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
-    uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream);
+    uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream,
+    bool requests = false);
 hipError_t launchLeafToBvh(const uint32_t* workLeaf, const TopLeafDev* leaves, uint32_t nLeaves, uint32_t* workBvh, uint32_t n, uint32_t blocks, hipStream_t stream);
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);

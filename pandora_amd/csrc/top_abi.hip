@@ -97,6 +97,18 @@ int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* c
 
 extern "C" {
 
+int pgpu_set_svdag_defer(pgpu_ctx* c, uint32_t min_rays, uint32_t passes)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    if (min_rays != 0u && (passes < 1u || passes > 8u))
+        return fail(c, PGPU_ERR_INVALID, "pgpu_set_svdag_defer: passes must be 1..8");
+    c->deferMin = min_rays;
+    if (min_rays != 0u)
+        c->deferPasses = passes;
+    return PGPU_OK;
+}
+
 int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags)
 {
     if (!c || !words || !dags || n_words == 0 || n_dags == 0)
@@ -145,18 +157,73 @@ int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const
         levels = std::max<uint32_t>(levels, height[dags[d].root]);
     }
     std::vector<SvdagDev> dev(n_dags);
+    // Per-DAG images for the cast kernel (TopDev::dagImages): breadth first from the root, local offsets, at most
+    // kDagImageMaxWords words; what does not fit is referred to in the shared array.
+    std::vector<uint32_t> images, order;
+    std::vector<int32_t> localOf(n_words, -1);
+    uint32_t imgMax = 0;
     for (size_t d = 0; d < n_dags; ++d) {
         dev[d].root = dags[d].root;
         for (int a = 0; a < 3; ++a)
             dev[d].bmin[a] = dags[d].bounds_min[a];
         dev[d].invExtent = dags[d].inv_extent;
         dev[d].levels = height[dags[d].root];
+        order.clear();
+        order.push_back(dags[d].root);
+        localOf[dags[d].root] = 0;
+        uint32_t used = 0;
+        auto nodeWords = [&](uint32_t at) {
+            const uint32_t desc = words[at];
+            return 1u + uint32_t(__builtin_popcount(((desc >> 8) & 0xFFu) & ~(desc & 0xFFu)));
+        };
+        used = nodeWords(dags[d].root);
+        if (used > kDagImageMaxWords) { // (cannot happen: a node has at most 9 words)
+            localOf[dags[d].root] = -1;
+            order.clear();
+            used = 0;
+        }
+        for (size_t i = 0; i < order.size(); ++i) {
+            const uint32_t at = order[i], nk = nodeWords(at) - 1u;
+            for (uint32_t k = 0; k < nk; ++k) {
+                const uint32_t kid = words[at + 1 + k];
+                if (localOf[kid] >= 0)
+                    continue;
+                const uint32_t sz = nodeWords(kid);
+                if (used + sz > kDagImageMaxWords)
+                    continue; // stays in the shared array
+                localOf[kid] = int32_t(used);
+                used += sz;
+                order.push_back(kid);
+            }
+        }
+        dev[d].img_offset = uint32_t(images.size());
+        dev[d].img_words = used;
+        images.resize(images.size() + used);
+        uint32_t* img = images.data() + dev[d].img_offset;
+        for (uint32_t at : order) {
+            const uint32_t base = uint32_t(localOf[at]), nk = nodeWords(at) - 1u;
+            img[base] = words[at];
+            for (uint32_t k = 0; k < nk; ++k) {
+                const uint32_t kid = words[at + 1 + k];
+                img[base + 1 + k] = localOf[kid] >= 0 ? uint32_t(localOf[kid]) : (kid | kDagGlobalFlag);
+            }
+        }
+        for (uint32_t at : order)
+            localOf[at] = -1;
+        imgMax = std::max(imgMax, used);
     }
-    uint32_t* dw = nullptr;
+    if (n_words >= kDagGlobalFlag)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: more than 2^31 words");
+    uint32_t *dw = nullptr, *di = nullptr;
     SvdagDev* dd = nullptr;
     int rc = uploadOwned(c, words, n_words, &dw);
     if (rc != PGPU_OK)
         return rc;
+    rc = uploadOwned(c, images.data(), images.size(), &di);
+    if (rc != PGPU_OK)
+        return rc;
+    c->top.dagImages = di;
+    c->top.img_max_words = imgMax;
     rc = uploadOwned(c, dev.data(), n_dags, &dd);
     if (rc != PGPU_OK)
         return rc;
@@ -264,6 +331,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     const size_t oWorkRay = carve(n * 4), oWorkBvh = carve(n * 4), oWorkLeaf = carve(n * 4);
     const size_t oLeafCount = carve(nl * 4), oLeafStart = carve(nl * 4), oLeafFill = carve(nl * 4);
     const size_t oParkedCount = carve(256), oCounters = carve(256);
+    // deferred casts: the requests sorted by batching point, and per point their count / first / fill + the total
+    const size_t oReqList = carve(n * 4), oReqCount = carve(nl * 4), oReqStart = carve(nl * 4), oReqFill = carve(nl * 4), oUnitStart = carve(nl * 4), oReqTotal = carve(256);
     size_t oRays = 0, oHits = 0;
     if (mem == PGPU_MEM_HOST) {
         oRays = carve(n * 8 * 4);
@@ -285,6 +354,12 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     uint32_t* dLeafFill = reinterpret_cast<uint32_t*>(wb + oLeafFill);
     uint32_t* dParkedCount = reinterpret_cast<uint32_t*>(wb + oParkedCount);
     unsigned long long* dCounters = reinterpret_cast<unsigned long long*>(wb + oCounters);
+    uint32_t* dReqList = reinterpret_cast<uint32_t*>(wb + oReqList);
+    uint32_t* dReqCount = reinterpret_cast<uint32_t*>(wb + oReqCount);
+    uint32_t* dReqStart = reinterpret_cast<uint32_t*>(wb + oReqStart);
+    uint32_t* dReqFill = reinterpret_cast<uint32_t*>(wb + oReqFill);
+    uint32_t* dUnitStart = reinterpret_cast<uint32_t*>(wb + oUnitStart);
+    uint32_t* dReqTotal = reinterpret_cast<uint32_t*>(wb + oReqTotal);
 
     float* dT = nullptr;
     uint32_t *dObj = nullptr, *dLeaf = nullptr, *dVisits = nullptr, *dAny = nullptr, *dInst = nullptr;
@@ -389,12 +464,55 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     // blocks of 256 per CU the top-level kernel can keep resident: LDS (160 KiB) and registers (64 VGPRs: 8 waves per SIMD)
     const uint32_t topPerCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
     const uint32_t topMaxBlocks = uint32_t(c->numCUs) * topPerCU;
+    CastArgs ca {};
+    ca.top = c->top;
+    ca.ox = rp[0];
+    ca.oy = rp[1];
+    ca.oz = rp[2];
+    ca.dx = rp[3];
+    ca.dy = rp[4];
+    ca.dz = rp[5];
+    ca.parked_leaf = dParkedLeaf;
+    ca.visits = dVisits;
+    ca.leaf_count = dLeafCount;
+    ca.counters = dCounters;
+    ca.req_list = dReqList;
+    ca.req_start = dReqStart;
+    ca.req_count = dReqCount;
+    ca.unit_start = dUnitStart;
+    ca.plan = dReqTotal;
+    ta.req_leaf_count = dReqCount;
+    const uint32_t castPerCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / ((svdagCastLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
     while (nActive > 0) {
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
         ta.active = active;
         ta.n_active = nActive;
         ta.may_park = rounds < nl ? 1u : 0u; // a ray pauses at most once per batching point
-        HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u)), stream));
+        const uint32_t topBlocks = std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u));
+        // pgpu_set_svdag_defer (off unless asked for: measured slower than casts inside the episode).
+        // Large passes with proxy geometry: the episode stops at every batching point that has an SVDAG, the requests are binned
+        // by point and cast by a kernel that stages the point's DAG in LDS, and the rays whose cast missed (culled) go on --
+        // twice; whatever is still on its way after that finishes with the casts inside the episode, as small passes do from
+        // the start. (Inside an episode every trip of every lane reads 4 bytes of some DAG: a cache line per lane and trip.)
+        const bool defer = c->deferMin != 0u && c->top.n_dags > 0 && ta.may_park != 0u && nActive >= c->deferMin;
+        ta.only_culled = 0u;
+        if (defer) {
+            const uint32_t binBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nActive + 255u) / 256u));
+            const uint32_t castBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * castPerCU, uint32_t(nActive / 2048u + nl)));
+            ca.active = active;
+            for (uint32_t pass = 0; pass < c->deferPasses; ++pass) {
+                HIP_TRY(c, hipMemsetAsync(dReqCount, 0, nl * 4, stream));
+                ta.only_culled = pass ? 1u : 0u;
+                HIP_TRY(c, launchTopTraverse(ta, kind, topBlocks, stream, true));
+                HIP_TRY(c, launchSvdagPlan(dReqCount, dReqStart, dReqFill, dUnitStart, uint32_t(nl), dReqTotal, stream));
+                // (positions, not ray ids: the cast kernel updates parked_leaf[position]; the bvh / leaf outputs are scratch here)
+                HIP_TRY(c, launchBinByLeaf(nullptr, dParkedLeaf, nActive, uint32_t(nl), dReqStart, dReqFill, c->top.leaves, dReqList, dWorkBvh, dWorkLeaf,
+                               binBlocks, stream, true));
+                HIP_TRY(c, launchSvdagCast(ca, castBlocks, stream));
+            }
+            ta.only_culled = 1u;
+        }
+        HIP_TRY(c, launchTopTraverse(ta, kind, topBlocks, stream));
         // The scan and the binning do not depend on the host knowing the count: queue them behind the traversal,
         // then fetch the number of parked rays (it sizes the bottom-level launch and ends the loop).
         HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), dParkedCount, stream));

@@ -36,105 +36,153 @@ __device__ __forceinline__ float stdmin(float a, float b) { return b < a ? b : a
 __device__ __forceinline__ float stdmax(float a, float b) { return a < b ? b : a; }
 __device__ __forceinline__ float exp2i(int e) { return __uint_as_float(uint32_t(e + 127) << 23); }
 
-// sparse_voxel_dag.cpp:350-567 with three lanes. `saved` is this lane's column of the parent stack.
-__device__ bool svdagHit(const uint32_t* __restrict__ words, const SvdagDev& dag, float rox, float roy, float roz,
-    float rdx, float rdy, float rdz, uint32_t* saved, uint32_t savedStride)
+// sparse_voxel_dag.cpp:350-567 with three lanes, cut into "set up" and "one trip of the loop" so that the same code serves the
+// cast inside the top-level episode (run to completion per lane) and the cast kernel (lanes take new requests as their casts
+// finish). Results: 0 = still running, 1 = hit, 2 = miss.
+// Where a cast reads its nodes: the shared array (index = offset there), or one DAG's image staged in LDS, whose nodes refer
+// to each other by local offset and to nodes that did not fit by kDagGlobalFlag | offset in the shared array (everything
+// below such a node is read from the shared array; its offsets carry no flag there, so the flag is added on the way).
+struct GlobalDag {
+    const uint32_t* __restrict__ words;
+    __device__ __forceinline__ uint32_t node(uint32_t p) const { return words[p]; }
+    __device__ __forceinline__ uint32_t child(uint32_t p, uint32_t k) const { return words[p + 1u + k]; }
+};
+struct StagedDag {
+    const uint32_t* lds;
+    const uint32_t* __restrict__ words;
+    __device__ __forceinline__ uint32_t node(uint32_t p) const { return (p & kDagGlobalFlag) ? words[p & ~kDagGlobalFlag] : lds[p]; }
+    __device__ __forceinline__ uint32_t child(uint32_t p, uint32_t k) const
+    {
+        return (p & kDagGlobalFlag) ? (words[(p & ~kDagGlobalFlag) + 1u + k] | kDagGlobalFlag) : lds[p + 1u + k];
+    }
+};
+
+struct CastState {
+    float tCoef[3], tBias[3], pos[3];
+    float tMin;
+    uint32_t idx, parent, desc, octBits, trips, tripCap;
+    int scale;
+};
+
+template <typename Dag>
+__device__ __forceinline__ int castInit(CastState& s, const Dag& words, uint32_t root, const SvdagDev& dag, float rox, float roy, float roz,
+    float rdx, float rdy, float rdz)
 {
     const float eps = 1.1920928955078125e-07f;
     float o[3] = { 1.0f + (dag.invExtent * (rox - dag.bmin[0])), 1.0f + (dag.invExtent * (roy - dag.bmin[1])), 1.0f + (dag.invExtent * (roz - dag.bmin[2])) };
     float d[3] = { rdx, rdy, rdz };
-    float tCoef[3], tBias[3], pos[3];
     uint32_t octMask = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         if (fabsf(d[i]) < eps)
             d[i] = copysignf(eps, d[i]);
-        tCoef[i] = 1.0f / -fabsf(d[i]);
-        tBias[i] = tCoef[i] * o[i];
+        s.tCoef[i] = 1.0f / -fabsf(d[i]);
+        s.tBias[i] = s.tCoef[i] * o[i];
         if (d[i] > 0.0f) {
             octMask |= 1u << i;
-            tBias[i] = 3.0f * tCoef[i] - tBias[i];
+            s.tBias[i] = 3.0f * s.tCoef[i] - s.tBias[i];
         }
     }
-    const uint32_t octBits = (7u ^ octMask) & 7u;
-    const float tMin0 = stdmax(0.0f, stdmax(2.0f * tCoef[0] - tBias[0], stdmax(2.0f * tCoef[1] - tBias[1], 2.0f * tCoef[2] - tBias[2])));
-    const float tMax0 = stdmin(tCoef[0] - tBias[0], stdmin(tCoef[1] - tBias[1], tCoef[2] - tBias[2]));
+    s.octBits = (7u ^ octMask) & 7u;
+    const float tMin0 = stdmax(0.0f, stdmax(2.0f * s.tCoef[0] - s.tBias[0], stdmax(2.0f * s.tCoef[1] - s.tBias[1], 2.0f * s.tCoef[2] - s.tBias[2])));
+    const float tMax0 = stdmin(s.tCoef[0] - s.tBias[0], stdmin(s.tCoef[1] - s.tBias[1], s.tCoef[2] - s.tBias[2]));
     if (tMin0 >= tMax0)
-        return false;
-    float tMin = tMin0;
-    uint32_t idx = 0;
+        return 2;
+    s.tMin = tMin0;
+    s.idx = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const bool m = (1.5f * tCoef[i] - tBias[i]) > tMin0;
-        idx |= uint32_t(m) << i;
-        pos[i] = m ? 1.5f : 1.0f;
+        const bool m = (1.5f * s.tCoef[i] - s.tBias[i]) > tMin0;
+        s.idx |= uint32_t(m) << i;
+        s.pos[i] = m ? 1.5f : 1.0f;
     }
-    uint32_t parent = dag.root;
-    int scale = kCastDepth - 1;
+    s.parent = root;
+    // the descriptor word of `parent`: fetched when the cast arrives at a node (PUSH, POP), not in every trip -- an ADVANCE
+    // that stays inside the node (the common trip in a sparse DAG) costs no memory access at all
+    s.desc = words.node(s.parent);
+    s.scale = kCastDepth - 1;
     // with NaN operands an ADVANCE makes no progress: after this many trips give up and do not cull (deviation 4)
-    const uint32_t tripCap = (16u * dag.levels + 16u) << dag.levels;
-    uint32_t trips = 0;
-    while (scale < kCastDepth) {
-        if (++trips > tripCap)
-            return true;
-        float tCorner[3];
+    s.tripCap = (16u * dag.levels + 16u) << dag.levels;
+    s.trips = 0;
+    return 0;
+}
+
+// one trip of the loop (:425-540); `saved` is this lane's column of the parent stack. Precondition: s.scale < kCastDepth.
+template <typename Dag>
+__device__ __forceinline__ int castTrip(CastState& s, const Dag& words, uint32_t* saved, uint32_t savedStride)
+{
+    if (++s.trips > s.tripCap)
+        return 1;
+    float tCorner[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            tCorner[i] = pos[i] * tCoef[i] - tBias[i];
-        const uint32_t child = 7u - ((idx & 7u) ^ octBits);
-        const uint32_t desc = words[parent];
-        const uint32_t valid = (desc >> 8) & 0xFFu, leaf = desc & 0xFFu;
-        if (valid >> child & 1u) {
-            // PUSH
-            const float half = exp2i((scale - 1) - kCastDepth);
-            saved[uint32_t(kCastDepth - 1 - scale) * savedStride] = parent;
-            if ((valid & leaf) >> child & 1u)
-                return true;
-            const uint32_t inner = valid & ~leaf;
-            parent = words[parent + 1u + __popc(inner & ((1u << child) - 1u))];
-            --scale;
-            idx = 0;
+    for (int i = 0; i < 3; ++i)
+        tCorner[i] = s.pos[i] * s.tCoef[i] - s.tBias[i];
+    const uint32_t child = 7u - ((s.idx & 7u) ^ s.octBits);
+    const uint32_t valid = (s.desc >> 8) & 0xFFu, leaf = s.desc & 0xFFu;
+    if (valid >> child & 1u) {
+        // PUSH
+        const float half = exp2i((s.scale - 1) - kCastDepth);
+        saved[uint32_t(kCastDepth - 1 - s.scale) * savedStride] = s.parent;
+        if ((valid & leaf) >> child & 1u)
+            return 1;
+        const uint32_t inner = valid & ~leaf;
+        s.parent = words.child(s.parent, __popc(inner & ((1u << child) - 1u)));
+        s.desc = words.node(s.parent);
+        --s.scale;
+        s.idx = 0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float tCenter = half * tCoef[i] + tCorner[i];
-                const bool m = tCenter > tMin;
-                idx |= uint32_t(m) << i;
-                pos[i] = m ? pos[i] + half : pos[i];
-            }
-        } else {
-            // ADVANCE
-            const float size = exp2i(scale - kCastDepth);
-            const float tcMax = stdmin(tCorner[0], stdmin(tCorner[1], tCorner[2]));
-            uint32_t step = 0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const bool s = tCorner[i] <= tcMax;
-                step |= uint32_t(s) << i;
-                pos[i] = s ? pos[i] - size : pos[i];
-            }
-            tMin = tcMax;
-            idx ^= step;
-            if ((idx & step) != 0) {
-                // POP
-                uint32_t diff = 0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    if (step >> i & 1u)
-                        diff |= __float_as_uint(pos[i]) ^ __float_as_uint(pos[i] + size);
-                scale = 31 - __clz(int(diff));
-                if (scale < kCastDepth)
-                    parent = saved[uint32_t(kCastDepth - 1 - scale) * savedStride];
-            }
-            uint32_t sh[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                sh[i] = __float_as_uint(pos[i]) >> scale;
-                pos[i] = __uint_as_float(sh[i] << scale);
-            }
-            idx = (sh[0] & 1u) | ((sh[1] & 1u) << 1) | ((sh[2] & 1u) << 2);
+        for (int i = 0; i < 3; ++i) {
+            const float tCenter = half * s.tCoef[i] + tCorner[i];
+            const bool m = tCenter > s.tMin;
+            s.idx |= uint32_t(m) << i;
+            s.pos[i] = m ? s.pos[i] + half : s.pos[i];
         }
+    } else {
+        // ADVANCE
+        const float size = exp2i(s.scale - kCastDepth);
+        const float tcMax = stdmin(tCorner[0], stdmin(tCorner[1], tCorner[2]));
+        uint32_t step = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const bool st = tCorner[i] <= tcMax;
+            step |= uint32_t(st) << i;
+            s.pos[i] = st ? s.pos[i] - size : s.pos[i];
+        }
+        s.tMin = tcMax;
+        s.idx ^= step;
+        if ((s.idx & step) != 0) {
+            // POP
+            uint32_t diff = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (step >> i & 1u)
+                    diff |= __float_as_uint(s.pos[i]) ^ __float_as_uint(s.pos[i] + size);
+            s.scale = 31 - __clz(int(diff));
+            if (s.scale < kCastDepth) {
+                s.parent = saved[uint32_t(kCastDepth - 1 - s.scale) * savedStride];
+                s.desc = words.node(s.parent);
+            }
+        }
+        uint32_t sh[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            sh[i] = __float_as_uint(s.pos[i]) >> s.scale;
+            s.pos[i] = __uint_as_float(sh[i] << s.scale);
+        }
+        s.idx = (sh[0] & 1u) | ((sh[1] & 1u) << 1) | ((sh[2] & 1u) << 2);
     }
-    return false;
+    return s.scale < kCastDepth ? 0 : 2;
+}
+
+__device__ bool svdagHit(const uint32_t* __restrict__ words, const SvdagDev& dag, float rox, float roy, float roz,
+    float rdx, float rdy, float rdz, uint32_t* saved, uint32_t savedStride)
+{
+    CastState s;
+    const GlobalDag g { words };
+    int r = castInit(s, g, dag.root, dag, rox, roy, roz, rdx, rdy, rdz);
+    while (r == 0)
+        r = castTrip(s, g, saved, savedStride);
+    return r == 1;
 }
 
 // simd4_avx2.ipp:412-430 (horizontalMinIndex): lane-wise two-round min, first lane equal to it, default 3
@@ -185,7 +233,7 @@ __device__ __forceinline__ KeyGroup groupByKey(uint32_t key, bool active)
     return kg;
 }
 
-template <bool ANY, bool NODES_IN_LDS>
+template <bool ANY, bool NODES_IN_LDS, bool DEFER>
 __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void topTraverseKernel(TopTraceArgs a)
 {
     // dynamic LDS: [dag_levels x 256 saved parents of the SVDAG cast][the top-level nodes, when they fit]
@@ -195,6 +243,7 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     unsigned char* const ldsNodes = topLds + size_t(a.top.dag_levels) * kTopBlock * 4u;
     uint32_t* const ldsCount = reinterpret_cast<uint32_t*>(ldsNodes + (NODES_IN_LDS ? ((size_t(a.top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u));
     const bool countInLds = a.top.n_leaves <= kTopHistMax;
+    uint32_t* const ldsReqCount = ldsCount + 2u + a.top.n_leaves; // DEFER, countInLds: cast requests per batching point
     if (NODES_IN_LDS) {
         const uint32_t words = a.top.n_nodes * (kTopNodeBytes / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.top.nodes);
@@ -202,7 +251,7 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         for (uint32_t i = threadIdx.x; i < words; i += kTopBlock)
             dst[i] = src[i];
     }
-    for (uint32_t i = threadIdx.x; i < 2u + (countInLds ? a.top.n_leaves : 0u); i += kTopBlock)
+    for (uint32_t i = threadIdx.x; i < 2u + (countInLds ? a.top.n_leaves * (DEFER ? 2u : 1u) : 0u); i += kTopBlock)
         ldsCount[i] = 0u;
     __syncthreads();
     const unsigned char* nodeBase = NODES_IN_LDS ? ldsNodes : a.top.nodes;
@@ -210,10 +259,11 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
 
     // (whole waves enter every trip: the parking step below uses wave-wide ballots)
     for (uint32_t w0 = blockIdx.x * kTopBlock; w0 < a.n_active; w0 += gridDim.x * kTopBlock) {
-        const uint32_t w = w0 + threadIdx.x;
-        const bool live = w < a.n_active;
+        const uint32_t w = w0 + threadIdx.x; // position in the round's list
+        // (only_culled: this pass advances the rays whose cast missed in the last one and leaves the others alone)
+        const bool live = w < a.n_active && (a.only_culled == 0u || a.parked_leaf[w] == kCastCulled);
         const uint32_t ray = live ? (a.active ? a.active[w] : w) : 0u;
-        bool parked = false;
+        bool parked = false, deferred = false;
         uint32_t leafId = 0;
         // a shadow ray already occluded in its last leaf is done (offline_batching...h:246-247)
         if (live && !(ANY && a.any_out[ray] != 0u)) {
@@ -270,6 +320,12 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                             const uint32_t leaf = nu[25] + __popc((valid & leafMask) & ((1u << child) - 1u));
                             const TopLeafDev lf = a.top.leaves[leaf];
                             bool culled = false;
+                            if (DEFER && lf.svdag != PGPU_MISS_ID) {
+                                // the cast kernel decides: parked here, or culled and on with the traversal from this token
+                                deferred = true;
+                                leafId = leaf;
+                                break;
+                            }
                             if (lf.svdag != PGPU_MISS_ID) {
                                 ++nTests;
                                 const SvdagDev dag = a.top.dags[lf.svdag];
@@ -294,16 +350,26 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                     break;
                 node = nu[26];
             }
-            if (parked) {
+            if (parked || deferred) {
                 a.node[ray] = node;
                 a.stack[ray] = stack;
-                if (a.visits)
+                if (a.visits && parked)
                     a.visits[ray] += 1u; // Ray::numTopLevelIntersections (:283)
             }
         }
         // park: the round's list keeps one entry per work item (the batching point, or none), one count per point
         if (live)
-            a.parked_leaf[w] = parked ? leafId : PGPU_MISS_ID;
+            a.parked_leaf[w] = parked ? leafId : (deferred ? (leafId | kCastRequestFlag) : PGPU_MISS_ID);
+        if (DEFER && __ballot(deferred) != 0) {
+            // one request count per batching point (they are binned by point for the cast kernel)
+            const KeyGroup kg = groupByKey(leafId, deferred);
+            if (deferred && kg.leader == (threadIdx.x & 63u)) {
+                if (countInLds)
+                    atomicAdd(&ldsReqCount[leafId], kg.size);
+                else
+                    atomicAdd(&a.req_leaf_count[leafId], kg.size);
+            }
+        }
         if (__ballot(parked) != 0) {
             const KeyGroup kg = groupByKey(leafId, parked);
             if (a.leaf_count && parked && kg.leader == (threadIdx.x & 63u)) {
@@ -326,6 +392,142 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         for (uint32_t i = threadIdx.x; i < a.top.n_leaves; i += kTopBlock)
             if (ldsCount[2u + i] != 0u)
                 atomicAdd(&a.leaf_count[i], ldsCount[2u + i]);
+    if (DEFER && countInLds)
+        for (uint32_t i = threadIdx.x; i < a.top.n_leaves; i += kTopBlock)
+            if (ldsReqCount[i] != 0u)
+                atomicAdd(&a.req_leaf_count[i], ldsReqCount[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The casts of one pass (see CastArgs in kernels.h): requests sorted by batching point, the point's DAG staged in LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kCastTripsPerPass = 8; // trips between two looks at who is done
+constexpr uint32_t kCastRefillMin = 12;   // idle lanes that make a refill worth its cost
+constexpr uint32_t kCastChunk = 64;       // requests a wave draws at a time from the unit's cursor
+constexpr uint32_t kCastUnit = 2048;      // requests of one batching point a block takes at a time
+
+__global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void svdagCastKernel(CastArgs a)
+{
+    // dynamic LDS: [the DAG image][dag_levels x 256 saved parents][cursor, hits of the run, tests, culled]
+    extern __shared__ __align__(16) unsigned char castLds[];
+    uint32_t* const image = reinterpret_cast<uint32_t*>(castLds);
+    uint32_t* const dagStack = image + a.top.img_max_words;
+    uint32_t* const ctl = dagStack + size_t(a.top.dag_levels) * kTopBlock; // [0] cursor [1] hits of this unit [2] tests [3] culled [4] unit
+    if (threadIdx.x < 5u)
+        ctl[threadIdx.x] = 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* const saved = dagStack + threadIdx.x;
+    // Work units: the requests of one batching point in pieces of kCastUnit (svdagPlanKernel numbered them: unit_start[l] =
+    // first unit of point l). Blocks draw units from a cursor until none is left, so a pass whose requests are spread thinly
+    // over many points still keeps every CU busy -- each unit has a fixed cost (staging the image, filling and draining the
+    // lanes) that is paid in parallel, not one after the other by the block that happens to own that stretch of the list.
+    const uint32_t nUnits = a.plan[0];
+    uint32_t nTests = 0, nCulled = 0;
+    {
+        for (;;) {
+            __syncthreads(); // the previous unit is done with the image and the control words
+            if (threadIdx.x == 0)
+                ctl[4] = atomicAdd(&a.plan[1], 1u);
+            __syncthreads();
+            const uint32_t unit = ctl[4];
+            if (unit >= nUnits)
+                break;
+            // the batching point that owns this unit: the last one whose first unit is <= unit (points without requests share
+            // their successor's number and sort before it)
+            uint32_t first = 0, last = a.top.n_leaves;
+            while (last - first > 1u) {
+                const uint32_t mid = (first + last) >> 1;
+                if (a.unit_start[mid] <= unit)
+                    first = mid;
+                else
+                    last = mid;
+            }
+            const uint32_t l = first;
+            const uint32_t start = a.req_start[l], count = a.req_count[l];
+            const uint32_t runLo = start + (unit - a.unit_start[l]) * kCastUnit, runHi = min(start + count, runLo + kCastUnit);
+            const SvdagDev dag = a.top.dags[a.top.leaves[l].svdag];
+            for (uint32_t i = threadIdx.x; i < dag.img_words; i += kTopBlock)
+                image[i] = a.top.dagImages[dag.img_offset + i];
+            if (threadIdx.x == 0) {
+                ctl[0] = runLo;
+                ctl[1] = 0u;
+            }
+            __syncthreads();
+            const StagedDag words { image, a.top.dagWords };
+            const uint32_t root = dag.img_words ? 0u : (dag.root | kDagGlobalFlag);
+            CastState s {};
+            bool busy = false;
+            int result = 0; // of a busy lane: 0 running, 1 hit, 2 miss
+            uint32_t w = 0, ray = 0, hits = 0;
+            uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
+            bool exhausted = false;
+            for (;;) {
+                const uint64_t idleMask = __ballot(!busy);
+                const uint32_t nIdle = uint32_t(__popcll(idleMask));
+                if (!exhausted && (nIdle >= kCastRefillMin || nIdle == 64u)) {
+                    if (chunkNext >= chunkEnd) {
+                        uint32_t c = 0;
+                        if (lane == 0)
+                            c = atomicAdd(&ctl[0], kCastChunk);
+                        c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
+                        if (c < runHi) {
+                            chunkNext = c;
+                            chunkEnd = min(c + kCastChunk, runHi);
+                        } else {
+                            exhausted = true;
+                        }
+                    }
+                    if (!exhausted) {
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idleMask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idleMask), 0u));
+                        const uint32_t at = chunkNext + rank;
+                        const bool take = !busy && at < chunkEnd;
+                        chunkNext = min(chunkNext + nIdle, chunkEnd);
+                        if (take) {
+                            w = a.req_list[at];
+                            ray = a.active ? a.active[w] : w;
+                            ++nTests;
+                            busy = true;
+                            result = castInit(s, words, root, dag, a.ox[ray], a.oy[ray], a.oz[ray], a.dx[ray], a.dy[ray], a.dz[ray]);
+                        }
+                    }
+                }
+                if (__ballot(busy) == 0) {
+                    if (exhausted)
+                        break;
+                    continue;
+                }
+                for (uint32_t k = 0; k < kCastTripsPerPass; ++k)
+                    if (busy && result == 0)
+                        result = castTrip(s, words, saved, kTopBlock);
+                if (busy && result == 1) {
+                    a.parked_leaf[w] = l; // parked at this batching point
+                    if (a.visits)
+                        a.visits[ray] += 1u; // Ray::numTopLevelIntersections (a ray has at most one request per pass)
+                    ++hits;
+                    busy = false;
+                } else if (busy && result == 2) {
+                    a.parked_leaf[w] = kCastCulled;
+                    ++nCulled;
+                    busy = false;
+                }
+            }
+            // hits of the run: wave sum, one LDS atomic per wave, one global atomic per block and run
+            for (int o = 32; o > 0; o >>= 1)
+                hits += uint32_t(__shfl_xor(int(hits), o));
+            if (lane == 0 && hits)
+                atomicAdd(&ctl[1], hits);
+            __syncthreads();
+            if (threadIdx.x == 0 && ctl[1] != 0u)
+                atomicAdd(&a.leaf_count[l], ctl[1]);
+        }
+    }
+    if (nTests)
+        atomicAdd(&ctl[2], nTests);
+    if (nCulled)
+        atomicAdd(&ctl[3], nCulled);
+    __syncthreads();
+    if (threadIdx.x < 2u && ctl[2u + threadIdx.x] != 0u)
+        atomicAdd(&a.counters[threadIdx.x], (unsigned long long)ctl[2u + threadIdx.x]);
 }
 
 // exclusive scan of leaf_count into leaf_start (single block; batching points number in the hundreds)
@@ -357,14 +559,22 @@ __global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* __restric
 }
 
 // scatter parked records into per-leaf contiguous ranges (the GPU form of the per-leaf queues)
+// what a position of the round's list is binned under: its batching point, or (requests) the point under kCastRequestFlag
+__device__ __forceinline__ uint32_t binKey(uint32_t v, bool requests)
+{
+    if (!requests)
+        return v;
+    return (v & kCastRequestFlag) ? (v & ~kCastRequestFlag) : PGPU_MISS_ID; // (PGPU_MISS_ID and kCastCulled stay out of range)
+}
+
 __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf,
     uint32_t n, uint32_t nLeaves, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
-    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf)
+    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf, bool requests)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {
         const uint32_t i = i0 + threadIdx.x;
-        const uint32_t leaf = i < n ? parkedLeaf[i] : PGPU_MISS_ID;
+        const uint32_t leaf = i < n ? binKey(parkedLeaf[i], requests) : PGPU_MISS_ID;
         const bool live = leaf < nLeaves; // (PGPU_MISS_ID = not parked; anything else out of range is ignored too)
         const KeyGroup kg = groupByKey(leaf, live);
         uint32_t base = 0;
@@ -384,7 +594,7 @@ __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restric
 // point in LDS, reserves one range per point it saw with a single global atomic, and hands out the slots from LDS.
 __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf,
     uint32_t n, uint32_t nLeaves, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
-    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf)
+    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf, bool requests)
 {
     extern __shared__ uint32_t binLds[]; // [nLeaves] running count, [nLeaves] first slot of this block's range
     uint32_t* const cnt = binLds;
@@ -397,7 +607,7 @@ __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __rest
     __syncthreads();
     for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
         const uint32_t i = i0 + threadIdx.x;
-        const uint32_t leaf = i < hi ? parkedLeaf[i] : PGPU_MISS_ID;
+        const uint32_t leaf = i < hi ? binKey(parkedLeaf[i], requests) : PGPU_MISS_ID;
         const bool live = leaf < nLeaves;
         if (__ballot(live) != 0) {
             const KeyGroup kg = groupByKey(leaf, live);
@@ -416,7 +626,7 @@ __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __rest
     __syncthreads();
     for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
         const uint32_t i = i0 + threadIdx.x;
-        const uint32_t leaf = i < hi ? parkedLeaf[i] : PGPU_MISS_ID;
+        const uint32_t leaf = i < hi ? binKey(parkedLeaf[i], requests) : PGPU_MISS_ID;
         const bool live = leaf < nLeaves;
         if (__ballot(live) == 0)
             continue;
@@ -469,26 +679,85 @@ bool topNodesFitLds(uint32_t nNodes) { return size_t(nNodes) * kTopNodeBytes <= 
 
 size_t topTraverseLdsBytes(const TopDev& top)
 {
+    // (the second per-point counter array is used by the deferred-cast variant only; it is small)
     return size_t(top.dag_levels) * kTopBlock * 4u + (topNodesFitLds(top.n_nodes) ? ((size_t(top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u)
-        + 8u + (top.n_leaves <= kTopHistMax ? size_t(top.n_leaves) * 4u : 0u);
+        + 8u + (top.n_leaves <= kTopHistMax ? size_t(top.n_leaves) * 8u : 0u);
 }
 
-hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream)
+hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, hipStream_t stream, bool defer)
 {
     const bool inLds = topNodesFitLds(a.top.n_nodes);
     const dim3 grid(blocks), block(kTopBlock);
     const size_t ldsBytes = topTraverseLdsBytes(a.top);
+#define PANDORA_TOP(ANYV, LDSV)                                                                                  \
+    do {                                                                                                         \
+        if (defer)                                                                                               \
+            hipLaunchKernelGGL((topTraverseKernel<ANYV, LDSV, true>), grid, block, ldsBytes, stream, a);        \
+        else                                                                                                     \
+            hipLaunchKernelGGL((topTraverseKernel<ANYV, LDSV, false>), grid, block, ldsBytes, stream, a);       \
+    } while (0)
     if (kind == PGPU_ANY_ID) {
         if (inLds)
-            hipLaunchKernelGGL((topTraverseKernel<true, true>), grid, block, ldsBytes, stream, a);
+            PANDORA_TOP(true, true);
         else
-            hipLaunchKernelGGL((topTraverseKernel<true, false>), grid, block, ldsBytes, stream, a);
+            PANDORA_TOP(true, false);
     } else {
         if (inLds)
-            hipLaunchKernelGGL((topTraverseKernel<false, true>), grid, block, ldsBytes, stream, a);
+            PANDORA_TOP(false, true);
         else
-            hipLaunchKernelGGL((topTraverseKernel<false, false>), grid, block, ldsBytes, stream, a);
+            PANDORA_TOP(false, false);
     }
+#undef PANDORA_TOP
+    return hipGetLastError();
+}
+
+size_t svdagCastLdsBytes(const TopDev& top) { return (size_t(top.img_max_words) + size_t(top.dag_levels) * kTopBlock + 8u) * 4u; }
+
+// exclusive scan of the request counts (first request per point, as leafScanKernel) and of the work units per point
+__global__ __launch_bounds__(1024) void svdagPlanKernel(const uint32_t* __restrict__ count, uint32_t* __restrict__ start, uint32_t* __restrict__ fill,
+    uint32_t* __restrict__ unitStart, uint32_t n, uint32_t* __restrict__ plan)
+{
+    __shared__ uint32_t part[1024], upart[1024];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(threadIdx.x * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0, usum = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        sum += count[i];
+        usum += (count[i] + kCastUnit - 1u) / kCastUnit;
+    }
+    part[threadIdx.x] = sum;
+    upart[threadIdx.x] = usum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u, u = threadIdx.x >= off ? upart[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        upart[threadIdx.x] += u;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum, urun = upart[threadIdx.x] - usum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        start[i] = run;
+        fill[i] = 0;
+        unitStart[i] = urun;
+        run += count[i];
+        urun += (count[i] + kCastUnit - 1u) / kCastUnit;
+    }
+    if (threadIdx.x == 1023) {
+        plan[0] = upart[1023]; // work units of the pass
+        plan[1] = 0u;          // the cast kernel's unit cursor
+    }
+}
+
+hipError_t launchSvdagPlan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t* unitStart, uint32_t n, uint32_t* plan, hipStream_t stream)
+{
+    hipLaunchKernelGGL(svdagPlanKernel, dim3(1), dim3(1024), 0, stream, count, start, fill, unitStart, n, plan);
+    return hipGetLastError();
+}
+
+hipError_t launchSvdagCast(const CastArgs& a, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(svdagCastKernel, dim3(blocks), dim3(kTopBlock), svdagCastLdsBytes(a.top), stream, a);
     return hipGetLastError();
 }
 
@@ -499,15 +768,16 @@ hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill
 }
 
 hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
-    uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream)
+    uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream,
+    bool requests)
 {
     if (nLeaves <= kTopHistMax) {
         hipLaunchKernelGGL(binByLeafLdsKernel, dim3(blocks), dim3(256), size_t(nLeaves) * 8u, stream, active, parkedLeaf, nActive, nLeaves, leafStart,
-            leafFill, leaves, workRay, workBvh, workLeaf);
+            leafFill, leaves, workRay, workBvh, workLeaf, requests);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, nLeaves, leafStart, leafFill, leaves,
-        workRay, workBvh, workLeaf);
+        workRay, workBvh, workLeaf, requests);
     return hipGetLastError();
 }
 

@@ -56,3 +56,30 @@ def test_two_level_matches_oracle(two_level, lanes, window, leaf_min):
         assert np.array_equal(_bits(got_any["visits"]), want_any["visits"]), f"{name}: any-hit visits differ"
         for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
             assert cnt_any[k] == want_any["counters"][k], f"{name}: any counter {k}"
+
+
+@pytest.mark.parametrize("passes", [1, 2, 3])
+def test_deferred_svdag_casts_match_oracle(two_level, passes):
+    """pgpu_set_svdag_defer: the casts as a kernel of their own (requests sorted by batching point, DAG staged in LDS) give the
+    same hits, visit counts and SVDAG counters as the casts inside the episode -- both are checked against the same oracle."""
+    ctx, mesh, tl, orc = two_level
+    ctx.set_ray_layout(4)
+    ctx.set_kernel_variant(0, 0, 0)
+    ctx.set_svdag_defer(1, passes)  # every pass, however small
+    try:
+        for name, rays in _ray_sets(mesh).items():
+            got, cnt = ctx.trace(rays)
+            want = orc.trace(rays, lanes=3)
+            for k in ("t", "obj", "leaf", "u", "v", "visits"):
+                bad = np.nonzero(_bits(got[k]) != _bits(want[k]))[0]
+                assert bad.size == 0, f"{name}: {k} differs on {bad.size} rays, first {bad[:5]}"
+            for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                assert cnt[k] == want["counters"][k], f"{name}: counter {k}: {cnt[k]} != {want['counters'][k]}"
+            got_any, cnt_any = ctx.trace(rays, kind=pa.capi.ANY)
+            want_any = orc.trace(rays, any_hit=True, lanes=3)
+            assert np.array_equal(_bits(got_any["hit"]), want_any["hit"]), f"{name}: any-hit differs"
+            assert np.array_equal(_bits(got_any["visits"]), want_any["visits"]), f"{name}: any-hit visits differ"
+            for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                assert cnt_any[k] == want_any["counters"][k], f"{name}: any counter {k}"
+    finally:
+        ctx.set_svdag_defer(0)
