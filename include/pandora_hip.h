@@ -399,6 +399,20 @@ int pgpu_lambert_bounce(pgpu_ctx*, uint32_t bvh_id, const pgpu_rays* rays_in, co
 int pgpu_splat_misses(pgpu_ctx*, unsigned long long* film, size_t n_pixels, const uint32_t* obj, const pgpu_paths* paths, size_t n, const float sky[3],
     void* stream);
 
+/* Memory, copies and streams for hosts without HIP of their own (no counterpart in the reference, which never leaves host
+ * memory; used by include/pandora_amd/gpu_acceleration_structure.hpp). pgpu_host_alloc gives pinned host memory: copies from
+ * and to it run at PCIe rate and asynchronously. pgpu_copy is hipMemcpyAsync(..., hipMemcpyDefault) on a stream made by
+ * pgpu_stream_create (never NULL); pgpu_stream_sync waits for it. A context is otherwise used by one host thread at a time;
+ * these eight keep no state in it and may run on other threads while a trace call is in flight on the same context. */
+int pgpu_host_alloc(pgpu_ctx*, size_t bytes, void** out);
+int pgpu_host_free(pgpu_ctx*, void* p);
+int pgpu_device_alloc(pgpu_ctx*, size_t bytes, void** out);
+int pgpu_device_free(pgpu_ctx*, void* p);
+int pgpu_stream_create(pgpu_ctx*, void** stream);
+int pgpu_stream_destroy(pgpu_ctx*, void* stream);
+int pgpu_copy(pgpu_ctx*, void* dst, const void* src, size_t bytes, void* stream);
+int pgpu_stream_sync(pgpu_ctx*, void* stream);
+
 /* Diagnostics: device time of the traversal kernels of the last trace call on this context, measured
  * with HIP events on the stream they ran on (ms); enables/disables visit counters. */
 float pgpu_last_kernel_ms(const pgpu_ctx*);

@@ -125,6 +125,14 @@ SYMBOLS = {
     "pgpu_route_merge": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Hits), C.c_void_p, C.c_void_p]),
     "pgpu_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "pgpu_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgpu_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pgpu_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgpu_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pgpu_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgpu_stream_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pgpu_stream_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pgpu_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pgpu_stream_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pgpu_set_stats": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "pgpu_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

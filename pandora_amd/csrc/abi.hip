@@ -1,5 +1,6 @@
 // C-ABI implementation: device context, scene upload, batch tracing. See include/pandora_hip.h.
 #include "context.h"
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -13,6 +14,9 @@ namespace pandora_hip {
 int fail(pgpu_ctx* c, int code, const char* what, hipError_t e)
 {
     if (c) {
+        // (the memory helpers of memory_abi.hip may fail on another thread while a trace call fails on this one)
+        static std::mutex errMutex;
+        std::lock_guard<std::mutex> lock(errMutex);
         c->err = what;
         if (e != hipSuccess) {
             c->err += ": ";

@@ -1,9 +1,16 @@
 // Exercises the C++ host adapter the way an integrator uses the reference's interface:
-// per-ray intersect()/intersectAny(), results through the four handlers, two bounces through flush().
+// per-ray intersect()/intersectAny() from several threads, results through the four handlers, bounces through flush().
+//   test_adapter                      two bounces + shadow rays on one GPU
+//   test_adapter multi                one context vs two contexts (replicated) vs two contexts (batching points sharded,
+//                                     exchange through host memory) on GPU 0: identical results per ray
+//   test_adapter throughput [n] [t]   t threads (default 16) push n rays (default 1e7); prints rays/s at the boundary
 // Exit code 0 = pass, 2 = no GPU (reported cleanly), 1 = failure.
 #include "pandora_amd/gpu_acceleration_structure.hpp"
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 
 using namespace pandora_amd;
@@ -16,81 +23,271 @@ struct ShadowState {
     int pixel;
 };
 
-static TriangleShape quad(float z, float half)
+static TriangleShape quad(float z, float half, float cx = 0.0f, float cy = 0.0f)
 {
     TriangleShape s;
-    s.positions = { -half, -half, z, half, -half, z, half, half, z, -half, half, z };
+    s.positions = { cx - half, cy - half, z, cx + half, cy - half, z, cx + half, cy + half, z, cx - half, cy + half, z };
     s.indices = { 0, 1, 2, 0, 2, 3 };
     return s;
 }
 
-int main()
+// a bumpy height field over [-1, 1]^2 around z = -2: res x res cells, two triangles each
+static TriangleShape terrain(int res)
+{
+    TriangleShape s;
+    for (int y = 0; y <= res; ++y)
+        for (int x = 0; x <= res; ++x) {
+            const float fx = -1.0f + 2.0f * float(x) / float(res), fy = -1.0f + 2.0f * float(y) / float(res);
+            s.positions.insert(s.positions.end(), { fx, fy, -2.0f + 0.15f * std::sin(9.0f * fx) * std::cos(7.0f * fy) });
+        }
+    for (int y = 0; y < res; ++y)
+        for (int x = 0; x < res; ++x) {
+            const uint32_t a = uint32_t(y * (res + 1) + x), b = a + 1, c = a + uint32_t(res + 1), d = c + 1;
+            s.indices.insert(s.indices.end(), { a, b, d, a, d, c });
+        }
+    return s;
+}
+
+static uint32_t lcg(uint32_t& s)
+{
+    s = s * 1664525u + 1013904223u;
+    return s >> 8;
+}
+
+static Ray cameraRay(int i)
+{
+    uint32_t s = uint32_t(i) * 2654435761u + 12345u;
+    Ray r;
+    r.origin[0] = -0.95f + 1.9f * float(lcg(s)) / 16777216.0f;
+    r.origin[1] = -0.95f + 1.9f * float(lcg(s)) / 16777216.0f;
+    r.origin[2] = 1.0f;
+    r.direction[0] = 0.3f * (float(lcg(s)) / 16777216.0f - 0.5f);
+    r.direction[1] = 0.3f * (float(lcg(s)) / 16777216.0f - 0.5f);
+    r.direction[2] = (i % 10 == 9) ? 1.0f : -1.0f; // every tenth ray looks away: miss
+    return r;
+}
+
+static int basic()
 {
     std::vector<TriangleShape> shapes;
     for (int i = 0; i < 8; ++i)
         shapes.push_back(quad(-1.0f - float(i), 1.0f + 0.25f * float(i)));
     std::atomic<int> hits { 0 }, misses { 0 }, anyHits { 0 }, anyMisses { 0 }, bad { 0 };
+    GpuAccelerationStructureBuilder builder(&shapes, 4, 16);
+    using Accel = GpuAccelerationStructure<BounceState, ShadowState>;
+    Accel* self = nullptr;
+    Accel accel = builder.build<BounceState, ShadowState>(
+        [&](const Ray& r, const RayHit& h, const BounceState& s) {
+            ++hits;
+            // rays start at z = +1 looking down -z: nearest quad is shape 0 at z = -1, t = 2
+            if (s.depth == 0 && (h.shapeID != 0 || std::fabs(r.tfar - 2.0f) > 1e-6f || h.geometricNormal[2] <= 0))
+                ++bad;
+            if (s.depth == 0) { // spawn a shadow ray back towards the origin side and one bounce (from a pool thread)
+                Ray sh;
+                sh.origin[0] = r.origin[0];
+                sh.origin[1] = r.origin[1];
+                sh.origin[2] = -0.999f;
+                sh.direction[2] = 1.0f;
+                self->intersectAny(sh, ShadowState { s.pixel });
+                Ray b = sh;
+                b.origin[2] = -1.001f;
+                b.direction[2] = -1.0f;
+                self->intersect(b, BounceState { s.pixel, 1 });
+            }
+            if (s.depth == 1 && (h.shapeID != 1 || std::fabs(r.tfar - 0.999f) > 1e-4f))
+                ++bad;
+        },
+        [&](const Ray&, const BounceState&) { ++misses; },
+        [&](const Ray& r, const ShadowState&) { ++anyHits; if (!(r.tfar < 0)) ++bad; },
+        [&](const Ray&, const ShadowState&) { ++anyMisses; });
+    self = &accel;
+    if (accel.numBatchingPoints() < 2) {
+        std::printf("expected several batching points\n");
+        return 1;
+    }
+    const int n = 1000;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < 4; ++t)
+        pool.emplace_back([&, t] {
+            for (int i = t; i < n; i += 4) {
+                Ray r;
+                r.origin[0] = -0.9f + 1.8f * float(i % 32) / 31.0f;
+                r.origin[1] = -0.9f + 1.8f * float(i / 32) / 31.0f;
+                r.origin[2] = 1.0f;
+                r.direction[2] = (i % 10 == 9) ? 1.0f : -1.0f; // every tenth ray looks away: miss
+                accel.intersect(r, BounceState { i, 0 });
+            }
+        });
+    for (auto& th : pool)
+        th.join();
+    size_t traced = 0;
+    while (accel.pending())
+        traced += accel.flush();
+    std::printf("traced %zu rays: hits %d misses %d anyHits %d anyMisses %d bad %d, svdag tests %llu culled %llu\n", traced, hits.load(),
+        misses.load(), anyHits.load(), anyMisses.load(), bad.load(), (unsigned long long)accel.counters().svdag_tests,
+        (unsigned long long)accel.counters().svdag_culled);
+    const int primaryHits = n - n / 10;
+    if (hits != 2 * primaryHits || misses != n / 10 || anyMisses != primaryHits || anyHits != 0 || bad != 0 || traced != size_t(n + 2 * primaryHits))
+        return 1;
+    std::printf("adapter ok\n");
+    return 0;
+}
+
+// per-ray outcome of one run, indexed by the caller's pixel
+struct Outcome {
+    std::vector<uint32_t> shape, prim, tBits, visits, shadow;
+    std::vector<float> nz;
+    pgpu_counters counters {};
+    size_t traced = 0;
+};
+
+static Outcome runScene(const std::vector<TriangleShape>& shapes, const AdapterOptions& opt, int n, unsigned pushThreads)
+{
+    Outcome out;
+    out.shape.assign(size_t(n), 0xFFFFFFFFu);
+    out.prim.assign(size_t(n), 0xFFFFFFFFu);
+    out.tBits.assign(size_t(n), 0u);
+    out.visits.assign(size_t(n), 0u);
+    out.shadow.assign(size_t(n), 2u);
+    out.nz.assign(size_t(n), 0.0f);
+    GpuAccelerationStructureBuilder builder(&shapes, 1024, 16, opt);
+    using Accel = GpuAccelerationStructure<BounceState, ShadowState>;
+    Accel* self = nullptr;
+    Accel accel = builder.build<BounceState, ShadowState>(
+        [&](const Ray& r, const RayHit& h, const BounceState& s) {
+            const size_t p = size_t(s.pixel);
+            out.shape[p] = h.shapeID;
+            out.prim[p] = h.primitiveID;
+            std::memcpy(&out.tBits[p], &r.tfar, 4);
+            out.visits[p] = uint32_t(r.numTopLevelIntersections);
+            out.nz[p] = h.geometricNormal[2];
+            Ray sh; // shadow ray from the hit point towards a light above the scene
+            for (int a = 0; a < 3; ++a)
+                sh.origin[a] = r.origin[a] + r.tfar * r.direction[a];
+            sh.origin[2] += 1e-3f;
+            sh.direction[0] = 0.2f;
+            sh.direction[1] = 0.1f;
+            sh.direction[2] = 1.0f;
+            self->intersectAny(sh, ShadowState { s.pixel });
+        },
+        [&](const Ray& r, const BounceState& s) { out.visits[size_t(s.pixel)] = uint32_t(r.numTopLevelIntersections); },
+        [&](const Ray&, const ShadowState& s) { out.shadow[size_t(s.pixel)] = 1u; },
+        [&](const Ray&, const ShadowState& s) { out.shadow[size_t(s.pixel)] = 0u; });
+    self = &accel;
+    std::vector<std::thread> pushers;
+    for (unsigned t = 0; t < pushThreads; ++t)
+        pushers.emplace_back([&, t] {
+            for (int i = int(t); i < n; i += int(pushThreads))
+                accel.intersect(cameraRay(i), BounceState { i, 0 });
+        });
+    for (auto& th : pushers)
+        th.join();
+    while (accel.pending()) {
+        out.traced += accel.flush();
+        const pgpu_counters& c = accel.counters();
+        out.counters.svdag_tests += c.svdag_tests;
+        out.counters.svdag_culled += c.svdag_culled;
+        out.counters.leaf_visits += c.leaf_visits;
+        out.counters.records_routed += c.records_routed;
+    }
+    return out;
+}
+
+static int multi()
+{
+    std::vector<TriangleShape> shapes;
+    shapes.push_back(terrain(96)); // 18432 triangles: 18+ batching points of <= 1024
+    for (int i = 0; i < 6; ++i)
+        shapes.push_back(quad(-0.5f - 0.2f * float(i), 0.15f, -0.6f + 0.25f * float(i), 0.3f - 0.1f * float(i)));
+    const int n = 200000;
+    AdapterOptions one;
+    one.batchRays = 65536; // several batches per flush: the pipeline's stages get reused
+    const Outcome a = runScene(shapes, one, n, 4);
+    AdapterOptions two = one;
+    two.devices = { 0, 0 };
+    const Outcome b = runScene(shapes, two, n, 4);
+    AdapterOptions sharded = two;
+    sharded.multiGpu = MultiGpu::LeafSharded;
+    sharded.hostStagedExchange = true;
+    const Outcome c = runScene(shapes, sharded, n, 4);
+    size_t hits = 0, shadowed = 0;
+    for (int i = 0; i < n; ++i) {
+        hits += a.shape[size_t(i)] != 0xFFFFFFFFu;
+        shadowed += a.shadow[size_t(i)] == 1u;
+    }
+    auto same = [&](const Outcome& x, const char* name) {
+        const bool ok = x.shape == a.shape && x.prim == a.prim && x.tBits == a.tBits && x.visits == a.visits && x.shadow == a.shadow && x.nz == a.nz
+            && x.traced == a.traced && x.counters.svdag_tests == a.counters.svdag_tests && x.counters.svdag_culled == a.counters.svdag_culled
+            && x.counters.leaf_visits == a.counters.leaf_visits;
+        std::printf("%s: %s (traced %zu, svdag tests %llu, leaf visits %llu, records routed %llu)\n", name, ok ? "identical" : "DIFFERENT", x.traced,
+            (unsigned long long)x.counters.svdag_tests, (unsigned long long)x.counters.leaf_visits, (unsigned long long)x.counters.records_routed);
+        return ok;
+    };
+    std::printf("one context: %zu of %d rays hit, %zu shadowed, traced %zu\n", hits, n, shadowed, a.traced);
+    const bool okB = same(b, "two contexts, scene replicated");
+    const bool okC = same(c, "two contexts, batching points sharded");
+    if (hits < size_t(n) / 2 || shadowed == 0 || shadowed == hits || !okB || !okC || c.counters.records_routed == 0)
+        return 1;
+    std::printf("adapter multi ok\n");
+    return 0;
+}
+
+static int throughput(size_t n, unsigned threads)
+{
+    std::vector<TriangleShape> shapes;
+    shapes.push_back(terrain(512)); // 524288 triangles
+    AdapterOptions opt;
+    GpuAccelerationStructureBuilder builder(&shapes, 32768, 32, opt);
+    using Accel = GpuAccelerationStructure<BounceState, ShadowState>;
+    struct alignas(64) Cell {
+        std::atomic<uint64_t> v { 0 };
+    };
+    std::vector<Cell> hitCells(64), missCells(64);
+    const auto t0 = std::chrono::steady_clock::now();
+    Accel accel = builder.build<BounceState, ShadowState>(
+        [&](const Ray&, const RayHit&, const BounceState& s) { hitCells[size_t(s.pixel) & 63].v.fetch_add(1, std::memory_order_relaxed); },
+        [&](const Ray&, const BounceState& s) { missCells[size_t(s.pixel) & 63].v.fetch_add(1, std::memory_order_relaxed); },
+        [&](const Ray&, const ShadowState&) {}, [&](const Ray&, const ShadowState&) {});
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pushers;
+    for (unsigned t = 0; t < threads; ++t)
+        pushers.emplace_back([&, t] {
+            const size_t lo = n * t / threads, hi = n * (t + 1) / threads;
+            for (size_t i = lo; i < hi; ++i)
+                accel.intersect(cameraRay(int(i)), BounceState { int(i), 0 });
+        });
+    for (auto& th : pushers)
+        th.join();
+    const auto t2 = std::chrono::steady_clock::now();
+    const size_t traced = accel.flush();
+    const auto t3 = std::chrono::steady_clock::now();
+    uint64_t hits = 0, misses = 0;
+    for (size_t i = 0; i < 64; ++i) {
+        hits += hitCells[i].v.load();
+        misses += missCells[i].v.load();
+    }
+    const double build = std::chrono::duration<double>(t1 - t0).count(), push = std::chrono::duration<double>(t2 - t1).count(),
+                 flush = std::chrono::duration<double>(t3 - t2).count();
+    std::printf("{\"adapter_throughput\": {\"rays\": %zu, \"push_threads\": %u, \"host_threads\": %u, \"batching_points\": %zu, \"build_s\": %.3f, "
+                "\"push_Mrays_s\": %.1f, \"flush_Mrays_s\": %.1f, \"end_to_end_Mrays_s\": %.1f, \"hits\": %llu, \"misses\": %llu}}\n",
+        traced, threads, accel.hostThreads(), accel.numBatchingPoints(), build, double(n) / push * 1e-6, double(n) / flush * 1e-6,
+        double(n) / (push + flush) * 1e-6, (unsigned long long)hits, (unsigned long long)misses);
+    if (traced != n || hits + misses != n || hits == 0 || misses < n / 10)
+        return 1;
+    std::printf("adapter throughput ok\n");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
     try {
-        GpuAccelerationStructureBuilder builder(&shapes, 4, 16);
-        using Accel = GpuAccelerationStructure<BounceState, ShadowState>;
-        Accel* self = nullptr;
-        Accel accel = builder.build<BounceState, ShadowState>(
-            [&](const Ray& r, const RayHit& h, const BounceState& s) {
-                ++hits;
-                // rays start at z = +1 looking down -z: nearest quad is shape 0 at z = -1, t = 2
-                if (s.depth == 0 && (h.shapeID != 0 || std::fabs(r.tfar - 2.0f) > 1e-6f || h.geometricNormal[2] <= 0))
-                    ++bad;
-                if (s.depth == 0) { // spawn a shadow ray back towards the origin side and one bounce
-                    Ray sh;
-                    sh.origin[0] = r.origin[0];
-                    sh.origin[1] = r.origin[1];
-                    sh.origin[2] = -0.999f;
-                    sh.direction[2] = 1.0f;
-                    self->intersectAny(sh, ShadowState { s.pixel });
-                    Ray b = sh;
-                    b.origin[2] = -1.001f;
-                    b.direction[2] = -1.0f;
-                    self->intersect(b, BounceState { s.pixel, 1 });
-                }
-                if (s.depth == 1 && (h.shapeID != 1 || std::fabs(r.tfar - 0.999f) > 1e-4f))
-                    ++bad;
-            },
-            [&](const Ray&, const BounceState&) { ++misses; },
-            [&](const Ray& r, const ShadowState&) { ++anyHits; if (!(r.tfar < 0)) ++bad; },
-            [&](const Ray&, const ShadowState&) { ++anyMisses; });
-        self = &accel;
-        if (accel.numBatchingPoints() < 2) {
-            std::printf("expected several batching points\n");
-            return 1;
-        }
-        const int n = 1000;
-        std::vector<std::thread> pool;
-        for (int t = 0; t < 4; ++t)
-            pool.emplace_back([&, t] {
-                for (int i = t; i < n; i += 4) {
-                    Ray r;
-                    r.origin[0] = -0.9f + 1.8f * float(i % 32) / 31.0f;
-                    r.origin[1] = -0.9f + 1.8f * float(i / 32) / 31.0f;
-                    r.origin[2] = 1.0f;
-                    r.direction[2] = (i % 10 == 9) ? 1.0f : -1.0f; // every tenth ray looks away: miss
-                    accel.intersect(r, BounceState { i, 0 });
-                }
-            });
-        for (auto& th : pool)
-            th.join();
-        size_t traced = 0;
-        while (accel.pending())
-            traced += accel.flush();
-        std::printf("traced %zu rays: hits %d misses %d anyHits %d anyMisses %d bad %d, svdag tests %llu culled %llu\n", traced, hits.load(),
-            misses.load(), anyHits.load(), anyMisses.load(), bad.load(), (unsigned long long)accel.counters().svdag_tests,
-            (unsigned long long)accel.counters().svdag_culled);
-        const int primaryHits = n - n / 10;
-        if (hits != 2 * primaryHits || misses != n / 10 || anyMisses != primaryHits || anyHits != 0 || bad != 0 || traced != size_t(n + 2 * primaryHits))
-            return 1;
+        if (argc > 1 && std::strcmp(argv[1], "multi") == 0)
+            return multi();
+        if (argc > 1 && std::strcmp(argv[1], "throughput") == 0)
+            return throughput(argc > 2 ? size_t(std::atof(argv[2])) : size_t(10000000), argc > 3 ? unsigned(std::atoi(argv[3])) : 16u);
+        return basic();
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
         return std::string(e.what()).find("pgpu_init") != std::string::npos ? 2 : 1;
     }
-    std::printf("adapter ok\n");
-    return 0;
 }

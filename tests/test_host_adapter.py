@@ -26,3 +26,24 @@ def test_adapter_reports_missing_gpu_cleanly():
 def test_adapter_two_bounces_and_shadow_rays_on_gpu():
     p = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "adapter ok" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_two_contexts_replicated_and_sharded_match_one_context():
+    """AdapterOptions::devices = {0, 0}: two contexts in one process (scene replicated, then batching points sharded with the
+    in-process exchange) deliver the same hit per ray as one context; several batches per flush reuse the pipeline stages."""
+    p = subprocess.run([EXE, "multi"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "adapter multi ok" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_throughput_16_threads_1e7_rays():
+    """16 threads push 1e7 rays through intersect() (per-thread buffers, no lock per ray), one flush() traces them in batches
+    with conversion, GPU and handlers overlapped. The program prints rays/s at the boundary; the test keeps the line."""
+    p = subprocess.run([EXE, "throughput", "1e7", "16"], capture_output=True, text=True, timeout=600)
+    print(p.stdout)
+    assert p.returncode == 0 and "adapter throughput ok" in p.stdout, p.stdout + p.stderr
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "adapter_throughput.json"), "w") as f:
+            f.write(next(l for l in p.stdout.splitlines() if l.startswith("{")) + "\n")
