@@ -25,7 +25,7 @@ for kern, ctrs in acc.items():
     for name in sorted(ctrs):
         vals = [v for _, v in sorted(ctrs[name])]
         tail = vals[1:] if len(vals) > 1 else vals  # first dispatch of bench.py is the primary-ray pass
-        print("  %-32s n=%d mean(all but first)=%.6g  last=%.6g" % (name, len(vals), sum(tail) / len(tail), vals[-1]))
+        print("  %-32s n=%d mean(all but first)=%.6g  last=%.6g  sum=%.6g" % (name, len(vals), sum(tail) / len(tail), vals[-1], sum(vals)))
 
 # HBM-side traffic of the dominant kernel, per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are
 # KiB at the L2's memory side; on gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane reads at 64
