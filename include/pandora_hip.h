@@ -427,9 +427,19 @@ int pgpu_set_tuning(pgpu_ctx*, int blocks_per_cu, int chunk); /* 0 = automatic (
  * spill to HBM), and how many rays of a wave must wait at a leaf before the wave runs its triangle code
  * (0 = automatic). Results do not depend on any of them. */
 int pgpu_set_kernel_variant(pgpu_ctx*, int refill_min, int stack_window, int leaf_min);
-/* Lanes of a wave64 that share one ray in the bottom-level kernel: 4 (16 rays per wave, node staged in LDS) or
- * 2 (32 rays per wave, node halves in registers, two triangles per lane). Results do not depend on it. */
+/* Lanes of a wave64 that share one ray in the bottom-level kernel: 4 (16 rays per wave, node staged in LDS),
+ * 2 (32 rays per wave, node halves in registers, two triangles per lane) or 0 (the default: 4 for a batch through one BVH,
+ * 2 for the per-batching-point work lists of the two-level loops). Results do not depend on it. */
 int pgpu_set_ray_layout(pgpu_ctx*, int lanes_per_ray);
+/* pgpu_trace on resident scenes queues each round's kernels before the host has read the previous round's parked count (the
+ * kernels take their list lengths from device memory), so the GPU never waits for that read; 0 restores the round-by-round
+ * loop, which streamed scenes and pgpu_set_svdag_defer always use. On by default. Results do not depend on it. */
+int pgpu_set_round_lookahead(pgpu_ctx*, int on);
+/* The top-level kernel of pgpu_trace: 1 = waves in lockstep (64 rays start an episode together and the wave waits for the
+ * slowest), 2 = lanes take the next ray as soon as theirs has parked or left, and a wave runs BVH4 steps and SVDAG cast trips
+ * as separate phases, 0 = automatic. refill_min = idle lanes of a wave before it fetches new rays, cast_trips = cast trips
+ * per cast phase (0 = defaults; variant 2 only). Results do not depend on any of them. */
+int pgpu_set_top_variant(pgpu_ctx*, int variant, int refill_min, int cast_trips);
 
 #ifdef __cplusplus
 }

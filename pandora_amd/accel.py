@@ -544,6 +544,15 @@ class Context:
         """Sums the int64 fixed-point films of all ranks in place (pgpu_film_allreduce)."""
         _check(self._L.pgpu_film_allreduce(self._h, capi.ptr(film), int(film.numel() // 3), stream), self._h)
 
+    def set_top_variant(self, variant: int = 0, refill_min: int = 0, cast_trips: int = 0):
+        """Top-level kernel of trace(): 1 lockstep waves, 2 lanes refilled as their rays finish, 0 automatic. Same results."""
+        _check(self._L.pgpu_set_top_variant(self._h, variant, refill_min, cast_trips), self._h)
+
+    def set_round_lookahead(self, on: bool = True):
+        """trace() on resident scenes queues rounds ahead of the host's knowledge of the parked counts (default); False =
+        one host read per round before the next is queued. Same results."""
+        _check(self._L.pgpu_set_round_lookahead(self._h, int(on)), self._h)
+
     def set_svdag_defer(self, min_rays: int = 0, passes: int = 2):
         """Where trace() runs the SVDAG casts: 0 = inside the top-level episode (default); > 0 = passes of at least that many
         rays cast in a kernel of their own, `passes` times per round (pgpu_set_svdag_defer). Same results bit for bit."""

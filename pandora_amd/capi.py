@@ -149,6 +149,8 @@ SYMBOLS = {
     "pgpu_trace_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Rays), C.c_size_t, C.POINTER(Hits), C.c_void_p, C.POINTER(Counters), C.c_void_p]),
     "pgpu_film_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgpu_set_keep_shading": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgpu_set_round_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgpu_set_top_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pgpu_set_svdag_defer": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "pgpu_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),
     "pgpu_lambert_bounce": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Rays), C.POINTER(Hits), C.c_size_t, C.POINTER(C.c_float), C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),

@@ -174,7 +174,10 @@ void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8T
 {
     const uint32_t need = stackEntriesForDepth(depth);
     const uint32_t window = stackWindow(need, c->stackWindow);
-    const uint32_t lanes = c->hasInstances ? 4u : c->lanesPerRay; // (instance leaves: quad layout only)
+    // Layout. Instance leaves: quad only. Automatic: quad (16 rays per wave) for a whole batch through one BVH, where the kernel is
+    // bound by instruction issue; pair (32 rays per wave) for the work lists of the two-level loops, whose short traversals are
+    // bound by the latency of fetching rays and roots -- twice the rays in flight per wave measured 6 % faster there.
+    const uint32_t lanes = c->hasInstances ? 4u : (c->lanesPerRay ? c->lanesPerRay : (a.work_ray ? 2u : 4u));
     a.lanes_per_ray = lanes;
     a.instanced = c->hasInstances ? 1u : 0u;
     a.stack_entries = window;
@@ -284,6 +287,11 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipFree(c->cacheArena);
     if (c->copyDone)
         (void)hipEventDestroy(c->copyDone);
+    for (hipEvent_t e : c->roundEv)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (c->roundCounts)
+        (void)hipHostFree(c->roundCounts);
     if (c->copyStream)
         (void)hipStreamDestroy(c->copyStream);
     for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv })
@@ -334,9 +342,17 @@ int pgpu_set_kernel_variant(pgpu_ctx* c, int refill_min, int stack_window, int l
     return PGPU_OK;
 }
 
+int pgpu_set_round_lookahead(pgpu_ctx* c, int on)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    c->roundLookahead = on != 0;
+    return PGPU_OK;
+}
+
 int pgpu_set_ray_layout(pgpu_ctx* c, int lanes_per_ray)
 {
-    if (!c || (lanes_per_ray != 2 && lanes_per_ray != 4))
+    if (!c || (lanes_per_ray != 0 && lanes_per_ray != 2 && lanes_per_ray != 4))
         return PGPU_ERR_INVALID;
     c->lanesPerRay = uint32_t(lanes_per_ray);
     return PGPU_OK;

@@ -305,7 +305,8 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
     const lds_u8 *rdNearX = pairEven, *rdNearY = pairEven, *rdNearZ = pairEven;
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     uint32_t range = blockIdx.x & 7u;     // blocks are dealt round-robin over the 8 XCDs
-    bool exhausted = false;
+    // (a launch sized before the list's length was known: blocks the list cannot feed leave without probing the cursors)
+    bool exhausted = a.n_work_dev != nullptr && blockIdx.x >= max(8u, (min(*a.n_work_dev, a.n_work) + 2u * kRaysPerWave * 4u - 1u) / (2u * kRaysPerWave * 4u));
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
 
     // Ray set-up for the BVH `bd`: lane q of the quad brings component q of the origin (va) and of the direction (vb); lane 3
@@ -351,7 +352,13 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
                 if (lane == 0)
                     c = atomicAdd(a.cursor + range * 8u, a.chunk);
                 c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
-                const uint32_t lo = range * a.range_size, hi = min(lo + a.range_size, a.n_work);
+                // (n_work_dev: the list's length is known on the device only -- rounds queued ahead of the host's knowledge)
+                uint32_t nWork = a.n_work, rangeSize = a.range_size;
+                if (a.n_work_dev) {
+                    nWork = min(*a.n_work_dev, a.n_work);
+                    rangeSize = (((nWork + 7u) / 8u + a.chunk - 1u) / a.chunk) * a.chunk;
+                }
+                const uint32_t lo = range * rangeSize, hi = min(lo + rangeSize, nWork);
                 if (lo < hi && c < hi - lo) {
                     chunkNext = lo + c;
                     chunkEnd = min(chunkNext + a.chunk, hi);
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
     int st = 0; // 0 idle, 1 traversing, 2 waiting at a popped leaf, 3 popped an inner node (inside one step)
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     uint32_t range = blockIdx.x & 7u;
-    bool exhausted = false;
+    bool exhausted = a.n_work_dev != nullptr && blockIdx.x >= max(8u, (min(*a.n_work_dev, a.n_work) + 2u * kPairRaysPerWave * 4u - 1u) / (2u * kPairRaysPerWave * 4u));
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
 
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -836,7 +843,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                 if (lane == 0)
                     c = atomicAdd(a.cursor + range * 8u, a.chunk);
                 c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
-                const uint32_t lo = range * a.range_size, hi = min(lo + a.range_size, a.n_work);
+                // (n_work_dev: the list's length is known on the device only -- rounds queued ahead of the host's knowledge)
+                uint32_t nWork = a.n_work, rangeSize = a.range_size;
+                if (a.n_work_dev) {
+                    nWork = min(*a.n_work_dev, a.n_work);
+                    rangeSize = (((nWork + 7u) / 8u + a.chunk - 1u) / a.chunk) * a.chunk;
+                }
+                const uint32_t lo = range * rangeSize, hi = min(lo + rangeSize, nWork);
                 if (lo < hi && c < hi - lo) {
                     chunkNext = lo + c;
                     chunkEnd = min(chunkNext + a.chunk, hi);

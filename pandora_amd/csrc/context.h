@@ -41,7 +41,7 @@ struct pgpu_ctx {
     int blocksPerCU = 0; // 0 = as many as LDS / registers allow
     uint32_t chunk = 0; // work items a wave draws at a time, 0 = automatic
     uint32_t refillMin = 0; // 0: automatic
-    uint32_t lanesPerRay = 4; // bottom-level kernel layout: 4 = 16 rays per wave, 2 = 32 rays per wave
+    uint32_t lanesPerRay = 0; // bottom-level kernel layout: 4 = 16 rays per wave, 2 = 32 rays per wave, 0 = automatic (planBvh8LaunchShape)
     uint32_t leafMin = 0; // 0: automatic
     int stackWindow = 0;     // LDS stack entries per ray, 0 = automatic
     DeviceBuffer spill;      // global overflow of the per-ray stacks
@@ -90,6 +90,14 @@ struct pgpu_ctx {
     std::vector<CacheSlot> slots;
     hipStream_t copyStream = nullptr;
     hipEvent_t copyDone = nullptr;
+    // top-level kernel (pgpu_set_top_variant): 0 automatic, 1 lockstep waves, 2 lanes refilled as their rays finish
+    int topVariant = 0;
+    uint32_t topRefillMin = 16, topCastTrips = 4;
+    // pgpu_trace queues rounds ahead of the host (pgpu_set_round_lookahead): per-round parked counts in pinned memory
+    bool roundLookahead = true;
+    uint32_t* roundCounts = nullptr;
+    size_t roundCountsCap = 0;
+    hipEvent_t roundEv[2] = { nullptr, nullptr };
     std::vector<hipEvent_t> launchEvents; // ring: one event per bottom-level launch of the streaming path (a later record of the
     size_t launchEventNext = 0;           // same ring entry is a later point of the compute stream, so waiting on it stays safe)
     uint64_t useClock = 0;

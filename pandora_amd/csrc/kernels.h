@@ -48,6 +48,7 @@ struct Bvh8TraceArgs {
     uint32_t fixed_bvh;
     uint32_t n_bvhs;   // work items naming a bvh id beyond this are skipped (geometry not resident here)
     uint32_t n_work;
+    const uint32_t* n_work_dev; // optional: the real number of work items (<= n_work, which then only sizes the launch)
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
     float* t_out;
     uint32_t* obj_out;
@@ -106,6 +107,7 @@ struct TopTraceArgs {
     TopDev top;
     const uint32_t* active; // ray ids to advance (nullptr: identity)
     uint32_t n_active;
+    const uint32_t* n_active_dev; // optional: the real number of work items (<= n_active, which then only sizes the launch)
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
     const float* tfar_state; // closest-hit: current ray.tfar
     uint32_t* node;          // PauseableBVHInsertHandle.first  (pauseable_bvh.h:8)
@@ -126,6 +128,9 @@ struct TopTraceArgs {
     // in the previous pass (parked_leaf == kCastCulled); the others are left as they are.
     uint32_t only_culled;
     uint32_t* req_leaf_count;
+    // topTraverseLanesKernel (lanes refilled as their rays finish) instead of the lockstep kernel: idle lanes of a wave before
+    // it fetches new rays (0 = use the lockstep kernel), cast trips per turn of the cast phase
+    uint32_t lanes_refill_min, lanes_cast_trips;
 };
 
 // The SVDAG casts of one pass as a kernel of their own. Requests (positions of the round's list) arrive sorted by batching
@@ -159,7 +164,7 @@ hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill
 // requests = true: bins the positions whose parked_leaf carries kCastRequestFlag (by the batching point under the flag)
 hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream,
-    bool requests = false);
+    bool requests = false, const uint32_t* nActiveDev = nullptr);
 hipError_t launchLeafToBvh(const uint32_t* workLeaf, const TopLeafDev* leaves, uint32_t nLeaves, uint32_t* workBvh, uint32_t n, uint32_t blocks, hipStream_t stream);
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);

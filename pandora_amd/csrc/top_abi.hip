@@ -3,6 +3,8 @@
 // that replaces the reference's TaskGraph flush loop (task_graph.cpp:19-56) around
 // OfflineBatchingAccelerationStructure (offline_batching_acceleration_structure.h:158-260,406-437).
 #include "context.h"
+#include <limits>
+#include <cmath>
 #include <algorithm>
 #include <cstring>
 
@@ -96,6 +98,16 @@ int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* c
 } // namespace
 
 extern "C" {
+
+int pgpu_set_top_variant(pgpu_ctx* c, int variant, int refill_min, int cast_trips)
+{
+    if (!c || variant < 0 || variant > 2 || refill_min < 0 || refill_min > 64 || cast_trips < 0 || cast_trips > 64)
+        return PGPU_ERR_INVALID;
+    c->topVariant = variant;
+    c->topRefillMin = refill_min ? uint32_t(refill_min) : 16u;
+    c->topCastTrips = cast_trips ? uint32_t(cast_trips) : 4u;
+    return PGPU_OK;
+}
 
 int pgpu_set_svdag_defer(pgpu_ctx* c, uint32_t min_rays, uint32_t passes)
 {
@@ -422,6 +434,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ta.leaf_count = dLeafCount;
     ta.step_cap = uint32_t(std::min<uint64_t>(0xFFFFFFF0ull, 8ull * (uint64_t(c->top.n_nodes) + c->top.n_leaves) + 64ull));
     ta.counters = dCounters;
+    ta.lanes_refill_min = c->topVariant == 2 ? c->topRefillMin : 0u;
+    ta.lanes_cast_trips = c->topCastTrips;
 
     Bvh8TraceArgs ba {};
     ba.bvhs = c->bvhTable;
@@ -483,6 +497,63 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ca.plan = dReqTotal;
     ta.req_leaf_count = dReqCount;
     const uint32_t castPerCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / ((svdagCastLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
+    // Rounds queued ahead of the host (resident scenes, casts inside the episode). A round's kernels take the length of their
+    // work list from device memory -- the previous round's parked count -- and their launch size from the newest count the host
+    // has seen (counts never grow), so the host reads a round's count a whole round late, after the next round is queued: the GPU
+    // never waits for that read. The round queued behind the first empty one runs empty (a few launches of nothing).
+    if (!streaming && c->deferMin == 0u && c->roundLookahead) {
+        if (c->roundCountsCap < nl + 8) {
+            if (c->roundCounts)
+                HIP_TRY(c, hipHostFree(c->roundCounts));
+            c->roundCounts = nullptr;
+            c->roundCountsCap = 0;
+            HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->roundCounts), (nl + 8) * sizeof(uint32_t), hipHostMallocDefault));
+            c->roundCountsCap = nl + 8;
+        }
+        for (hipEvent_t& e : c->roundEv)
+            if (!e)
+                HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        uint32_t bound = uint32_t(n); // no round from here on has more work items than this
+        for (size_t r = 0; r + 4 < c->roundCountsCap; ++r) {
+            uint32_t* const countOut = dParkedCount + (r & 1u);
+            const uint32_t* const countIn = r ? dParkedCount + ((r - 1) & 1u) : nullptr;
+            HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
+            ta.active = active;
+            ta.n_active = bound;
+            ta.n_active_dev = countIn;
+            ta.may_park = r < nl ? 1u : 0u; // a ray pauses at most once per batching point
+            ta.only_culled = 0u;
+            const uint32_t listBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (bound + 255u) / 256u));
+            HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (bound + 255u) / 256u)), stream));
+            HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), countOut, stream));
+            uint32_t* const workRayOut = (active == dWorkRay) ? dWorkRayAlt : dWorkRay;
+            HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, bound, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
+                           listBlocks, stream, false, countIn));
+            HIP_TRY(c, hipMemcpyAsync(&c->roundCounts[r], countOut, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipEventRecord(c->roundEv[r & 1u], stream));
+            HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+            ba.work_ray = workRayOut;
+            ba.n_work = bound;
+            ba.n_work_dev = countOut;
+            ba.chunk = c->chunk;
+            uint32_t blocks = 1;
+            rc = planBvh8Launch(c, deepest, bound, ba, &blocks);
+            if (rc != PGPU_OK)
+                return rc;
+            HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+            active = workRayOut;
+            if (r >= 1) {
+                HIP_TRY(c, hipEventSynchronize(c->roundEv[(r - 1) & 1u]));
+                const uint32_t parked = c->roundCounts[r - 1];
+                if (parked == 0)
+                    break; // round r - 1 parked nothing: the traversal was over, round r ran empty
+                ++rounds;
+                leafVisits += parked;
+                bound = parked;
+            }
+        }
+        nActive = 0; // (skips the loop below)
+    }
     while (nActive > 0) {
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
         ta.active = active;

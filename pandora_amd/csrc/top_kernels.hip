@@ -206,6 +206,27 @@ __device__ __forceinline__ uint32_t hminIndex4(const float v[4])
     return 3;
 }
 
+// pauseable_bvh4.h:262-286: the four children's slab tests of one ray -- compare + select in the operand order of x86 minps /
+// maxps, which is what the reference's simd4 executes (the order decides which operand a NaN replaces). An IEEE min3 / max3
+// form for waves whose rays cannot produce a NaN (as in the bottom-level kernel) was measured: it needs two more registers than
+// the 64 that keep 8 waves per SIMD resident, and this kernel lives on occupancy -- 7.24 ms per step against 7.08 ms.
+__device__ __forceinline__ uint32_t slabs4(const float* nf, float ox, float oy, float oz, float ix, float iy, float iz, float tnear, float tfar, float tmin[4])
+{
+    uint32_t hitMask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float tx1 = (nf[0 + i] - ox) * ix, tx2 = (nf[12 + i] - ox) * ix;
+        const float ty1 = (nf[4 + i] - oy) * iy, ty2 = (nf[16 + i] - oy) * iy;
+        const float tz1 = (nf[8 + i] - oz) * iz, tz2 = (nf[20 + i] - oz) * iz;
+        const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
+        const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
+        tmin[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin)));
+        const float tmax = min86(tfar, min86(txMax, min86(tyMax, tzMax)));
+        hitMask |= uint32_t(tmin[i] <= tmax) << i;
+    }
+    return hitMask;
+}
+
 // Many rays of a wave usually want the same counter (coherent rays park at the same batching point), and
 // same-address atomics from single lanes serialise in L2. Lanes with equal keys therefore elect a leader that adds
 // the group's size once; every lane learns its leader, its rank inside the group and the group size.
@@ -244,6 +265,9 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     uint32_t* const ldsCount = reinterpret_cast<uint32_t*>(ldsNodes + (NODES_IN_LDS ? ((size_t(a.top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u));
     const bool countInLds = a.top.n_leaves <= kTopHistMax;
     uint32_t* const ldsReqCount = ldsCount + 2u + a.top.n_leaves; // DEFER, countInLds: cast requests per batching point
+    const uint32_t nActive = a.n_active_dev ? min(*a.n_active_dev, a.n_active) : a.n_active;
+    if (blockIdx.x * kTopBlock >= nActive)
+        return; // (a launch sized before the list's length was known: nothing here for this block, skip the staging too)
     if (NODES_IN_LDS) {
         const uint32_t words = a.top.n_nodes * (kTopNodeBytes / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(a.top.nodes);
@@ -258,10 +282,10 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     uint32_t nTests = 0, nCulled = 0;
 
     // (whole waves enter every trip: the parking step below uses wave-wide ballots)
-    for (uint32_t w0 = blockIdx.x * kTopBlock; w0 < a.n_active; w0 += gridDim.x * kTopBlock) {
+    for (uint32_t w0 = blockIdx.x * kTopBlock; w0 < nActive; w0 += gridDim.x * kTopBlock) {
         const uint32_t w = w0 + threadIdx.x; // position in the round's list
         // (only_culled: this pass advances the rays whose cast missed in the last one and leaves the others alone)
-        const bool live = w < a.n_active && (a.only_culled == 0u || a.parked_leaf[w] == kCastCulled);
+        const bool live = w < nActive && (a.only_culled == 0u || a.parked_leaf[w] == kCastCulled);
         const uint32_t ray = live ? (a.active ? a.active[w] : w) : 0u;
         bool parked = false, deferred = false;
         uint32_t leafId = 0;
@@ -287,18 +311,7 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 bool descended = false;
                 if (interest != 0) {
                     float tmin[4];
-                    uint32_t hitMask = 0;
-    #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float tx1 = (nf[0 + i] - ox) * ix, tx2 = (nf[12 + i] - ox) * ix;
-                        const float ty1 = (nf[4 + i] - oy) * iy, ty2 = (nf[16 + i] - oy) * iy;
-                        const float tz1 = (nf[8 + i] - oz) * iz, tz2 = (nf[20 + i] - oz) * iz;
-                        const float txMin = min86(tx1, tx2), tyMin = min86(ty1, ty2), tzMin = min86(tz1, tz2);
-                        const float txMax = max86(tx1, tx2), tyMax = max86(ty1, ty2), tzMax = max86(tz1, tz2);
-                        tmin[i] = max86(tnear, max86(txMin, max86(tyMin, tzMin)));
-                        const float tmax = min86(tfar, min86(txMax, min86(tyMax, tzMax)));
-                        hitMask |= uint32_t(tmin[i] <= tmax) << i;
-                    }
+                    const uint32_t hitMask = slabs4(nf, ox, oy, oz, ix, iy, iz, tnear, tfar, tmin);
                     const uint32_t toVisit = hitMask & uint32_t(interest) & valid;
                     if (toVisit != 0) {
                         uint32_t child;
@@ -396,6 +409,212 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         for (uint32_t i = threadIdx.x; i < a.top.n_leaves; i += kTopBlock)
             if (ldsReqCount[i] != 0u)
                 atomicAdd(&a.req_leaf_count[i], ldsReqCount[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same episode with lanes that never wait for their wave's slowest ray. Every lane is a small state machine -- idle,
+// walking the BVH4, or inside an SVDAG cast -- and a wave repeats: give idle lanes the next rays of its chunk; then run ONE of
+// the two phases, the one more of its lanes are waiting for: a BVH4 step for the walkers, or a few cast trips for the casters
+// (the others sit the phase out; whichever side is left waiting grows until it is the majority, so nobody starves). In the
+// lockstep kernel above a wave is as slow as its slowest ray and runs both code paths for every mix of lanes: 29 % of its
+// VALU lane-cycles do work on incoherent rays (profiles/r2_pmc_summary_two_level.txt). The sequence of operations of each
+// ray is the same in both kernels, so are the results.
+// ---------------------------------------------------------------------------------------------------
+template <bool ANY, bool NODES_IN_LDS>
+__global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs a)
+{
+    extern __shared__ __align__(16) unsigned char topLds[];
+    uint32_t* const dagStack = reinterpret_cast<uint32_t*>(topLds);
+    unsigned char* const ldsNodes = topLds + size_t(a.top.dag_levels) * kTopBlock * 4u;
+    uint32_t* const ldsCount = reinterpret_cast<uint32_t*>(ldsNodes + (NODES_IN_LDS ? ((size_t(a.top.n_nodes) * kTopNodeBytes + 15u) & ~size_t(15)) : 16u));
+    const bool countInLds = a.top.n_leaves <= kTopHistMax;
+    const uint32_t nActive = a.n_active_dev ? min(*a.n_active_dev, a.n_active) : a.n_active;
+    if (blockIdx.x * kTopBlock >= nActive)
+        return;
+    if (NODES_IN_LDS) {
+        const uint32_t words = a.top.n_nodes * (kTopNodeBytes / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.top.nodes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(ldsNodes);
+        for (uint32_t i = threadIdx.x; i < words; i += kTopBlock)
+            dst[i] = src[i];
+    }
+    for (uint32_t i = threadIdx.x; i < 2u + (countInLds ? a.top.n_leaves : 0u); i += kTopBlock)
+        ldsCount[i] = 0u;
+    __syncthreads();
+    const unsigned char* nodeBase = NODES_IN_LDS ? ldsNodes : a.top.nodes;
+    const GlobalDag dagWords { a.top.dagWords };
+    uint32_t* const saved = dagStack + threadIdx.x;
+    uint32_t nTests = 0, nCulled = 0;
+
+    // work: chunks of 64 consecutive positions of the round's list, dealt round-robin over the waves of the grid
+    const uint32_t wavesTotal = gridDim.x * (kTopBlock / 64u);
+    uint32_t chunk = uint32_t(__builtin_amdgcn_readfirstlane(int(blockIdx.x * (kTopBlock / 64u) + (threadIdx.x >> 6))));
+    uint32_t chunkNext = chunk * 64u, chunkEnd = min(chunkNext + 64u, nActive);
+
+    int mode = 0; // 0 idle, 1 walking the BVH4, 2 inside an SVDAG cast
+    uint32_t w = 0, ray = 0, node = 0, steps = 0, castLeaf = 0;
+    uint64_t stack = 0;
+    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
+    CastState cs {};
+
+    for (;;) {
+        // ---------------------------------------------------------------- idle lanes take new rays
+        const uint64_t idle = __ballot(mode == 0);
+        const uint32_t nIdle = uint32_t(__popcll(idle));
+        const bool more = chunkNext < nActive;
+        if (nIdle == 64u && !more)
+            break;
+        if (more && (nIdle == 64u || nIdle >= a.lanes_refill_min)) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+            const uint32_t avail = chunkEnd - chunkNext;
+            const bool take = mode == 0 && rank < avail;
+            const uint32_t mine = chunkNext + rank;
+            chunkNext += min(nIdle, avail);
+            if (chunkNext >= chunkEnd) {
+                chunk += wavesTotal;
+                chunkNext = chunk * 64u;
+                chunkEnd = min(chunkNext + 64u, nActive);
+            }
+            if (take) {
+                w = mine;
+                ray = a.active ? a.active[w] : w;
+                if (ANY && a.any_out[ray] != 0u) {
+                    a.parked_leaf[w] = PGPU_MISS_ID; // a shadow ray already occluded in its last leaf is done (offline_batching...h:246-247)
+                } else {
+                    ox = a.ox[ray];
+                    oy = a.oy[ray];
+                    oz = a.oz[ray];
+                    tnear = a.tnear[ray];
+                    tfar = ANY ? a.tfar_in[ray] : a.tfar_state[ray]; // simdRay is rebuilt from the ray at every resume (:243-254)
+                    ix = 1.0f / a.dx[ray]; // :241
+                    iy = 1.0f / a.dy[ray];
+                    iz = 1.0f / a.dz[ray];
+                    node = a.node[ray];
+                    stack = a.stack[ray];
+                    steps = 0;
+                    mode = 1;
+                }
+            }
+        }
+
+        const uint32_t nWalk = uint32_t(__popcll(__ballot(mode == 1))), nCast = uint32_t(__popcll(__ballot(mode == 2)));
+        bool fin = false, parked = false;
+        uint32_t leafId = 0;
+        if (nWalk != 0u && nWalk >= nCast) {
+            // ------------------------------------------------------------ one BVH4 step (pauseable_bvh4.h:262-352)
+            if (mode == 1) {
+                if (++steps > a.step_cap) {
+                    fin = true; // non-terminating traversal (kernels.h): the ray leaves the top level
+                } else {
+                    const float* nf = reinterpret_cast<const float*>(nodeBase + size_t(node) * kTopNodeBytes);
+                    const uint32_t* nu = reinterpret_cast<const uint32_t*>(nf);
+                    const uint32_t bits = nu[27];
+                    const uint32_t valid = bits & 0xFu, leafMask = (bits >> 4) & 0xFu;
+                    const int bitPos = 4 * int((bits >> 8) & 0xFFu);
+                    const uint64_t interest = (stack >> bitPos) & 0xFull;
+                    bool descended = false;
+                    if (interest != 0) {
+                        float tmin[4];
+                        const uint32_t hitMask = slabs4(nf, ox, oy, oz, ix, iy, iz, tnear, tfar, tmin);
+                        const uint32_t toVisit = hitMask & uint32_t(interest) & valid;
+                        if (toVisit != 0) {
+                            uint32_t child;
+                            if (ANY) {
+                                child = (toVisit & 1u) ? 0u : ((toVisit & 2u) ? 1u : ((toVisit & 4u) ? 2u : 3u)); // bitScan4
+                            } else {
+                                float masked[4];
+    #pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    masked[i] = (toVisit >> i & 1u) ? tmin[i] : 3.4028234663852886e38f;
+                                child = hminIndex4(masked);
+                            }
+                            const uint64_t rest = uint64_t(toVisit) ^ (1ull << child);
+                            stack = stack ^ (interest << bitPos);
+                            stack = stack | (rest << bitPos);
+                            descended = true;
+                            if ((valid & ~leafMask) >> child & 1u) {
+                                node = nu[24] + __popc((valid & ~leafMask) & ((1u << child) - 1u));
+                            } else {
+                                // BatchingPoint::intersect (offline_batching...h:269-305): the proxy geometry decides
+                                const uint32_t leaf = nu[25] + __popc((valid & leafMask) & ((1u << child) - 1u));
+                                const TopLeafDev lf = a.top.leaves[leaf];
+                                if (lf.svdag != PGPU_MISS_ID) {
+                                    ++nTests;
+                                    const SvdagDev dag = a.top.dags[lf.svdag];
+                                    const int r = castInit(cs, dagWords, dag.root, dag, ox, oy, oz, a.dx[ray], a.dy[ray], a.dz[ray]);
+                                    if (r == 0) {
+                                        castLeaf = leaf;
+                                        mode = 2;
+                                    } else {
+                                        ++nCulled; // the ray misses the DAG's cube: the traversal goes on at the same node
+                                    }
+                                } else {
+                                    fin = true;
+                                    parked = a.may_park != 0u;
+                                    leafId = leaf;
+                                }
+                            }
+                        }
+                    }
+                    if (!descended) {
+                        stack = stack | (0xFFFFFFFFFFFFFFFFull << bitPos);
+                        if (stack == 0xFFFFFFFFFFFFFFFFull)
+                            fin = true;
+                        else
+                            node = nu[26];
+                    }
+                }
+            }
+        } else if (nCast != 0u) {
+            // ------------------------------------------------------------ a few trips of the casts (a trip is about a third of
+            // a BVH4 step and a cast takes tens of them: several per turn keep the loop's bookkeeping off them)
+            for (uint32_t k = 0; k < a.lanes_cast_trips; ++k) {
+                if (mode == 2 && !fin) {
+                    const int r = castTrip(cs, dagWords, saved, kTopBlock);
+                    if (r == 1) {
+                        fin = true;
+                        parked = a.may_park != 0u;
+                        leafId = castLeaf;
+                    } else if (r == 2) {
+                        ++nCulled;
+                        mode = 1; // culled: the traversal goes on at the same node
+                    }
+                }
+                if (__ballot(mode == 2 && !fin) == 0)
+                    break;
+            }
+        }
+
+        // ---------------------------------------------------------------- rays whose episode is over
+        if (fin) {
+            a.parked_leaf[w] = parked ? leafId : PGPU_MISS_ID;
+            if (parked) {
+                a.node[ray] = node;
+                a.stack[ray] = stack;
+                if (a.visits)
+                    a.visits[ray] += 1u; // Ray::numTopLevelIntersections (:283)
+                if (a.leaf_count) {
+                    if (countInLds)
+                        atomicAdd(&ldsCount[2u + leafId], 1u);
+                    else
+                        atomicAdd(&a.leaf_count[leafId], 1u);
+                }
+            }
+            mode = 0;
+        }
+    }
+    // one global update per block and counter instead of one per ray: same-address atomics serialise in L2
+    if (nTests)
+        atomicAdd(&ldsCount[0], nTests);
+    if (nCulled)
+        atomicAdd(&ldsCount[1], nCulled);
+    __syncthreads();
+    if (threadIdx.x < 2u && ldsCount[threadIdx.x] != 0u)
+        atomicAdd(&a.counters[threadIdx.x], (unsigned long long)ldsCount[threadIdx.x]);
+    if (countInLds && a.leaf_count)
+        for (uint32_t i = threadIdx.x; i < a.top.n_leaves; i += kTopBlock)
+            if (ldsCount[2u + i] != 0u)
+                atomicAdd(&a.leaf_count[i], ldsCount[2u + i]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -569,9 +788,12 @@ __device__ __forceinline__ uint32_t binKey(uint32_t v, bool requests)
 
 __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf,
     uint32_t n, uint32_t nLeaves, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
-    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf, bool requests)
+    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf, bool requests,
+    const uint32_t* __restrict__ nDev)
 {
     const uint32_t lane = threadIdx.x & 63u;
+    if (nDev)
+        n = min(n, *nDev);
     for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t leaf = i < n ? binKey(parkedLeaf[i], requests) : PGPU_MISS_ID;
@@ -594,12 +816,15 @@ __global__ __launch_bounds__(256) void binByLeafKernel(const uint32_t* __restric
 // point in LDS, reserves one range per point it saw with a single global atomic, and hands out the slots from LDS.
 __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf,
     uint32_t n, uint32_t nLeaves, const uint32_t* __restrict__ leafStart, uint32_t* __restrict__ leafFill,
-    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf, bool requests)
+    const TopLeafDev* __restrict__ leaves, uint32_t* __restrict__ workRay, uint32_t* __restrict__ workBvh, uint32_t* __restrict__ workLeaf, bool requests,
+    const uint32_t* __restrict__ nDev)
 {
     extern __shared__ uint32_t binLds[]; // [nLeaves] running count, [nLeaves] first slot of this block's range
     uint32_t* const cnt = binLds;
     uint32_t* const first = binLds + nLeaves;
     const uint32_t lane = threadIdx.x & 63u;
+    if (nDev)
+        n = min(n, *nDev);
     const uint32_t per = (((n + gridDim.x - 1u) / gridDim.x) + 255u) & ~255u;
     const uint32_t lo = min(blockIdx.x * per, n), hi = min(lo + per, n);
     for (uint32_t i = threadIdx.x; i < nLeaves; i += 256u)
@@ -691,7 +916,9 @@ hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, h
     const size_t ldsBytes = topTraverseLdsBytes(a.top);
 #define PANDORA_TOP(ANYV, LDSV)                                                                                  \
     do {                                                                                                         \
-        if (defer)                                                                                               \
+        if (!defer && a.lanes_refill_min != 0u)                                                                  \
+            hipLaunchKernelGGL((topTraverseLanesKernel<ANYV, LDSV>), grid, block, ldsBytes, stream, a);         \
+        else if (defer)                                                                                          \
             hipLaunchKernelGGL((topTraverseKernel<ANYV, LDSV, true>), grid, block, ldsBytes, stream, a);        \
         else                                                                                                     \
             hipLaunchKernelGGL((topTraverseKernel<ANYV, LDSV, false>), grid, block, ldsBytes, stream, a);       \
@@ -769,15 +996,15 @@ hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill
 
 hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream,
-    bool requests)
+    bool requests, const uint32_t* nActiveDev)
 {
     if (nLeaves <= kTopHistMax) {
         hipLaunchKernelGGL(binByLeafLdsKernel, dim3(blocks), dim3(256), size_t(nLeaves) * 8u, stream, active, parkedLeaf, nActive, nLeaves, leafStart,
-            leafFill, leaves, workRay, workBvh, workLeaf, requests);
+            leafFill, leaves, workRay, workBvh, workLeaf, requests, nActiveDev);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, nLeaves, leafStart, leafFill, leaves,
-        workRay, workBvh, workLeaf, requests);
+        workRay, workBvh, workLeaf, requests, nActiveDev);
     return hipGetLastError();
 }
 

@@ -83,3 +83,33 @@ def test_deferred_svdag_casts_match_oracle(two_level, passes):
                 assert cnt_any[k] == want_any["counters"][k], f"{name}: any counter {k}"
     finally:
         ctx.set_svdag_defer(0)
+
+
+@pytest.mark.parametrize("refill_min,cast_trips", [(0, 0), (1, 1), (64, 8), (7, 3)])
+def test_top_level_lanes_kernel_matches_oracle(two_level, refill_min, cast_trips):
+    """pgpu_set_top_variant(2): the top-level kernel whose lanes take the next ray as soon as theirs has parked or left, with
+    BVH4 steps and SVDAG cast trips as separate wave phases -- same hits, visit counts and SVDAG counters as the oracle, for
+    any refill threshold and phase length, with and without the rounds queued ahead."""
+    ctx, mesh, tl, orc = two_level
+    ctx.set_ray_layout(0)
+    ctx.set_kernel_variant(0, 0, 0)
+    ctx.set_top_variant(2, refill_min, cast_trips)
+    ctx.set_round_lookahead(refill_min != 7)
+    try:
+        for name, rays in _ray_sets(mesh).items():
+            got, cnt = ctx.trace(rays)
+            want = orc.trace(rays, lanes=3)
+            for k in ("t", "obj", "leaf", "u", "v", "visits"):
+                bad = np.nonzero(_bits(got[k]) != _bits(want[k]))[0]
+                assert bad.size == 0, f"{name}: {k} differs on {bad.size} rays, first {bad[:5]}"
+            for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                assert cnt[k] == want["counters"][k], f"{name}: counter {k}: {cnt[k]} != {want['counters'][k]}"
+            got_any, cnt_any = ctx.trace(rays, kind=pa.capi.ANY)
+            want_any = orc.trace(rays, any_hit=True, lanes=3)
+            assert np.array_equal(_bits(got_any["hit"]), want_any["hit"]), f"{name}: any-hit differs"
+            assert np.array_equal(_bits(got_any["visits"]), want_any["visits"]), f"{name}: any-hit visits differ"
+            for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                assert cnt_any[k] == want_any["counters"][k], f"{name}: any counter {k}"
+    finally:
+        ctx.set_top_variant(0)
+        ctx.set_round_lookahead(True)

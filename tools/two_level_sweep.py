@@ -1,0 +1,57 @@
+"""Times pgpu_trace on bench.py's configs[2] scene and diffuse batch under the bottom-level kernel's scheduling knobs.
+Usage: python tools/two_level_sweep.py  (prints one line per setting)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+import pandora_amd as pa
+
+blocks = int(os.environ.get("CITY_BLOCKS", "24"))
+side = int(os.environ.get("SIDE", "4096"))
+ctx = pa.accel.Context(0)
+dev = torch.device("cuda:0")
+mesh, tl = bench.city_scene(pa, blocks, svdag=int(os.environ.get("SVDAG", "64")))
+tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+prim = bench.city_camera(pa, blocks, side, 891379)
+first, _ = ctx.trace(torch.from_numpy(prim).to(dev))
+prim_id = tl.prim_ids_of(first["leaf"].cpu().numpy(), first["obj"].cpu().numpy())
+rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379)
+d_rays = torch.from_numpy(rays).to(dev)
+out, _ = ctx.trace(d_rays)
+
+
+d_prim = torch.from_numpy(prim).to(dev)
+out_any, _ = ctx.trace(d_rays, kind=pa.capi.ANY)
+out_prim, _ = ctx.trace(d_prim)
+
+
+def timed_one(r, o, kind, reps=6):
+    ctx.trace(r, out=o, kind=kind)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.trace(r, out=o, kind=kind)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def timed():
+    return timed_one(d_rays, out, pa.capi.CLOSEST)
+
+
+def timed_more():
+    return "any %.3f ms, primary %.3f ms" % (timed_one(d_rays, out_any, pa.capi.ANY), timed_one(d_prim, out_prim, pa.capi.CLOSEST))
+
+
+settings = [dict(), dict(), dict(top=2, trefill=32, trips=8)]
+for s in settings:
+    ctx.set_ray_layout(s.get("lanes", 0))
+    ctx.set_round_lookahead(bool(s.get("look", 1)))
+    ctx.set_top_variant(s.get("top", 1), s.get("trefill", 0), s.get("trips", 0))
+    ctx.set_kernel_variant(s.get("refill", 0), 0, s.get("leaf", 0))
+    ctx.set_tuning(s.get("bpc", 0), s.get("chunk", 0))
+    print(s, "%.3f ms" % timed(), timed_more(), flush=True)
