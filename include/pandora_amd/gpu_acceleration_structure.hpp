@@ -898,7 +898,11 @@ public:
                 flat.insert(flat.end(), g.begin(), g.end());
                 offs.push_back(flat.size());
             }
-            check(pgpu_build_svdags(pos.data(), nv, idx.data(), nt, flat.data(), offs.data(), nGroups, m_svdagRes, &hs), ctx0, "pgpu_build_svdags");
+            // voxeliser + octrees + DAG merge on the first GPU (resolutions above 256 only exist in the host builder)
+            if (m_svdagRes <= 256 && nGroups <= 65535)
+                check(pgpu_build_svdags_device(ctx0, pos.data(), nv, idx.data(), nt, flat.data(), offs.data(), nGroups, m_svdagRes, &hs), ctx0, "pgpu_build_svdags_device");
+            else
+                check(pgpu_build_svdags(pos.data(), nv, idx.data(), nt, flat.data(), offs.data(), nGroups, m_svdagRes, &hs), ctx0, "pgpu_build_svdags");
         }
         pgpu_host_bvh4* top = nullptr;
         int rc = pgpu_build_top_bvh4(bounds.data(), nGroups, &top);

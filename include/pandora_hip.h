@@ -100,6 +100,14 @@ typedef struct pgpu_host_svdags pgpu_host_svdags;
 int pgpu_build_svdags(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
     const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t resolution,
     pgpu_host_svdags** out);
+/* The same on the GPU of `ctx` (pandora_amd/csrc/svdag_build.hip): one thread per triangle voxelises, an occupancy pyramid in
+ * Morton order gives the octrees of all batching points at once, and the subtrees are hash-consed level by level in a device
+ * hash table. Same arguments (host arrays) and the same kind of result object; every DAG expands to the same voxels, has the
+ * same bounds and leaf promotions, and the merged array has the same number of words as pgpu_build_svdags' -- the order of
+ * the nodes inside the array is the builder's own. resolution 4..256, at most 65535 batching points. */
+int pgpu_build_svdags_device(pgpu_ctx*, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t resolution,
+    pgpu_host_svdags** out);
 const uint32_t* pgpu_host_svdags_words(const pgpu_host_svdags*, size_t* n_words);
 const pgpu_svdag_desc* pgpu_host_svdags_descs(const pgpu_host_svdags*, size_t* n_dags);
 size_t pgpu_host_svdags_words_before_compression(const pgpu_host_svdags*);

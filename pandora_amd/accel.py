@@ -260,7 +260,9 @@ class HostSvdags:
 SVDAG_DESC_DTYPE = np.dtype([("root", np.uint32), ("bounds_min", np.float32, 3), ("inv_extent", np.float32), ("resolution", np.uint32)])
 
 
-def build_svdags(pos, idx, groups: list[np.ndarray], resolution: int) -> HostSvdags:
+def build_svdags(pos, idx, groups: list[np.ndarray], resolution: int, device_ctx: "Context | None" = None) -> HostSvdags:
+    """Voxelisation + SVO + DAG merge of every group of triangles. device_ctx: build on that context's GPU
+    (pgpu_build_svdags_device) instead of the host; both give DAGs with the same voxels, bounds and word count."""
     L = capi.lib()
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
@@ -268,8 +270,12 @@ def build_svdags(pos, idx, groups: list[np.ndarray], resolution: int) -> HostSvd
     offs = np.zeros(len(groups) + 1, np.uint64)
     offs[1:] = np.cumsum([g.size for g in groups])
     h = C.c_void_p()
-    _check(L.pgpu_build_svdags(pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prims.ctypes.data, offs.ctypes.data, len(groups), resolution, C.byref(h)),
-           what="pgpu_build_svdags failed")
+    if device_ctx is not None:
+        _check(L.pgpu_build_svdags_device(device_ctx._h, pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prims.ctypes.data, offs.ctypes.data,
+                                          len(groups), resolution, C.byref(h)), device_ctx._h)
+    else:
+        _check(L.pgpu_build_svdags(pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prims.ctypes.data, offs.ctypes.data, len(groups), resolution, C.byref(h)),
+               what="pgpu_build_svdags failed")
     try:
         n = C.c_size_t()
         p = L.pgpu_host_svdags_words(h, C.byref(n))
@@ -684,9 +690,11 @@ class TwoLevelScene:
         return leaves[:, 0].copy()
 
 
-def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4, build_group=None) -> TwoLevelScene:
+def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4, build_group=None,
+                    svdag_device_ctx: "Context | None" = None) -> TwoLevelScene:
     """build_group: optional callable (group sizes: int array) -> bool array; only those batching points get a bottom-level
-    BVH8 here (the others stay None: they live on another rank). The cut, the top level and the SVDAGs are always whole."""
+    BVH8 here (the others stay None: they live on another rank). The cut, the top level and the SVDAGs are always whole.
+    svdag_device_ctx: build the SVDAGs on that context's GPU instead of the host."""
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
     group_of, ng = partition_prims(pos, idx, prims_per_batching_point)
@@ -710,7 +718,7 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
         bounds[g, :3] = v.min(axis=0)
         bounds[g, 3:] = v.max(axis=0)
     top = build_top_bvh4(bounds)
-    dags = build_svdags(pos, idx, groups, svdag_res) if svdag_res > 0 else None
+    dags = build_svdags(pos, idx, groups, svdag_res, device_ctx=svdag_device_ctx) if svdag_res > 0 else None
     return TwoLevelScene(groups, bvhs, top, dags, bounds)
 
 

@@ -103,7 +103,10 @@ struct pgpu_ctx {
     uint64_t useClock = 0;
 };
 
+struct pgpu_host_svdags;
 namespace pandora_hip {
+// wraps a finished DAG array as the object pgpu_build_svdags returns (pandora_amd/host/svdag_builder.cpp)
+pgpu_host_svdags* makeHostSvdags(std::vector<uint32_t>&& words, std::vector<pgpu_svdag_desc>&& descs, size_t wordsBeforeCompression);
 // Shared by every translation unit of the C ABI (defined in abi.hip).
 // fail: records the message pgpu_last_error returns and hands back `code`.
 int fail(pgpu_ctx* c, int code, const char* what, hipError_t e = hipSuccess);

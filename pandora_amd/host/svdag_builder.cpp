@@ -271,6 +271,21 @@ struct pgpu_host_svdags {
     size_t wordsBefore = 0;
 };
 
+} // extern "C"
+
+namespace pandora_hip {
+pgpu_host_svdags* makeHostSvdags(std::vector<uint32_t>&& words, std::vector<pgpu_svdag_desc>&& descs, size_t wordsBeforeCompression)
+{
+    auto* r = new pgpu_host_svdags();
+    r->words = std::move(words);
+    r->descs = std::move(descs);
+    r->wordsBefore = wordsBeforeCompression;
+    return r;
+}
+}
+
+extern "C" {
+
 int pgpu_build_svdags(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
     const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t resolution,
     pgpu_host_svdags** out)
