@@ -256,9 +256,9 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
         return owner_by_group["o"] == rank
 
     t0 = time.perf_counter()
+    ctx = pa.accel.Context(dev.index)
     mesh, tl = city_scene(pa, args.city_blocks, build_group=mine, svdag=args.svdag, ctx=ctx)
     owner = owner_by_group["o"][np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
-    ctx = pa.accel.Context(dev.index)
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
     sharded.comm_init(ctx, dev)  # RCCL communicator of the library's own; the unique id travels through torch.distributed
     ctx.comm_selftest()

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpandora_hip.so")
+LIB_PATH = os.environ.get("PANDORA_HIP_LIB") or os.path.join(_HERE, "lib", "libpandora_hip.so")  # (the override is for A/B runs of two builds)
 
 OK, ERR_INVALID, ERR_HIP, ERR_SINGLE_LEAF, ERR_DEPTH, ERR_NO_SCENE, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 CLOSEST, ANY = 0, 1

@@ -306,7 +306,7 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     uint32_t range = blockIdx.x & 7u;     // blocks are dealt round-robin over the 8 XCDs
     // (a launch sized before the list's length was known: blocks the list cannot feed leave without probing the cursors)
-    bool exhausted = a.n_work_dev != nullptr && blockIdx.x >= max(8u, (min(*a.n_work_dev, a.n_work) + 2u * kRaysPerWave * 4u - 1u) / (2u * kRaysPerWave * 4u));
+    bool exhausted = false;
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
 
     // Ray set-up for the BVH `bd`: lane q of the quad brings component q of the origin (va) and of the direction (vb); lane 3
@@ -352,12 +352,7 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
                 if (lane == 0)
                     c = atomicAdd(a.cursor + range * 8u, a.chunk);
                 c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
-                // (n_work_dev: the list's length is known on the device only -- rounds queued ahead of the host's knowledge)
-                uint32_t nWork = a.n_work, rangeSize = a.range_size;
-                if (a.n_work_dev) {
-                    nWork = min(*a.n_work_dev, a.n_work);
-                    rangeSize = (((nWork + 7u) / 8u + a.chunk - 1u) / a.chunk) * a.chunk;
-                }
+                const uint32_t nWork = a.n_work, rangeSize = a.range_size;
                 const uint32_t lo = range * rangeSize, hi = min(lo + rangeSize, nWork);
                 if (lo < hi && c < hi - lo) {
                     chunkNext = lo + c;
@@ -1202,6 +1197,8 @@ size_t bvh8TraceLdsBytes(uint32_t stackEntries, uint32_t lanesPerRay)
 hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
 {
     const dim3 grid(blocks), block(256);
+    if (args.n_work_dev && (args.lanes_per_ray != 2u || args.instanced))
+        return hipErrorInvalidValue; // (only the pair-layout kernel reads its list length from device memory)
     const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries, args.lanes_per_ray);
 #define PANDORA_LAUNCH(ANYV, TRIV, STATV)                                                                            \
     do {                                                                                                             \

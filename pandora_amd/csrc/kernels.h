@@ -48,7 +48,7 @@ struct Bvh8TraceArgs {
     uint32_t fixed_bvh;
     uint32_t n_bvhs;   // work items naming a bvh id beyond this are skipped (geometry not resident here)
     uint32_t n_work;
-    const uint32_t* n_work_dev; // optional: the real number of work items (<= n_work, which then only sizes the launch)
+    const uint32_t* n_work_dev; // optional, pair layout only: the real number of work items (<= n_work, which then only sizes the launch)
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
     float* t_out;
     uint32_t* obj_out;
