@@ -292,13 +292,18 @@ __global__ __launch_bounds__(256) void internKernel(LevelView v, Slot* __restric
         }
         const unsigned long long h = hashKey(nodeKey(v, node));
         uint32_t at = uint32_t(h) & tableMask;
+        // (look before the atomic: the lowest level has millions of nodes and at most 255 different keys -- once a key is in its
+        // slot and a low index has been seen there, later arrivals only read)
         for (;;) {
-            const unsigned long long prev = atomicCAS(&table[at].hash, 0ull, h);
+            unsigned long long prev = __hip_atomic_load(&table[at].hash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == 0ull)
+                prev = atomicCAS(&table[at].hash, 0ull, h);
             if (prev == 0ull || prev == h)
                 break;
             at = (at + 1u) & tableMask; // (the table is at most half full: the probe ends)
         }
-        if (table[at].offset == kNoOffset) // (offsets are written by emitKernel only: stable during this launch)
+        if (table[at].offset == kNoOffset // (offsets are written by sealKernel only: stable during this launch)
+            && __hip_atomic_load(&table[at].rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > node)
             atomicMin(&table[at].rep, node);
         slotOf[node] = at;
     }
