@@ -857,7 +857,9 @@ public:
         }));
 
         m.twoLevel = nGroups >= 2;
-        m.sharded = m.twoLevel && nDev > 1 && m_options.multiGpu == MultiGpu::LeafSharded;
+        // (LeafSharded with one device is allowed: one rank owns every batching point and the whole sharded loop, communicator
+        // included, runs -- how the RCCL path is exercised on a one-GPU box)
+        m.sharded = m.twoLevel && m_options.multiGpu == MultiGpu::LeafSharded;
         // owner of every batching point (sharded): heaviest first onto the least loaded GPU, as sharded.assign_leaves
         std::vector<uint32_t> ownerOfGroup(nGroups, 0);
         if (m.sharded) {

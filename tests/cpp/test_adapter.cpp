@@ -210,6 +210,9 @@ static int multi()
     sharded.multiGpu = MultiGpu::LeafSharded;
     sharded.hostStagedExchange = true;
     const Outcome c = runScene(shapes, sharded, n, 4);
+    AdapterOptions rccl = one; // one rank, but through pgpu_comm_init (RCCL) + pgpu_trace_sharded
+    rccl.multiGpu = MultiGpu::LeafSharded;
+    const Outcome r = runScene(shapes, rccl, n, 4);
     size_t hits = 0, shadowed = 0;
     for (int i = 0; i < n; ++i) {
         hits += a.shape[size_t(i)] != 0xFFFFFFFFu;
@@ -226,7 +229,8 @@ static int multi()
     std::printf("one context: %zu of %d rays hit, %zu shadowed, traced %zu\n", hits, n, shadowed, a.traced);
     const bool okB = same(b, "two contexts, scene replicated");
     const bool okC = same(c, "two contexts, batching points sharded");
-    if (hits < size_t(n) / 2 || shadowed == 0 || shadowed == hits || !okB || !okC || c.counters.records_routed == 0)
+    const bool okR = same(r, "one context, sharded loop over an RCCL communicator of one rank");
+    if (hits < size_t(n) / 2 || shadowed == 0 || shadowed == hits || !okB || !okC || !okR || c.counters.records_routed == 0)
         return 1;
     std::printf("adapter multi ok\n");
     return 0;
