@@ -158,7 +158,8 @@ int pgpu_upload_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint
  * (batching_acceleration_structure.h:411-422), and that is what is implemented: REF-UNPINNED.
  * Limits: one level (the instanced BVH holds no instances itself), an instance sits alone in its leaf (pgpu_build_bvh8_boxes
  * with the `alone` flag builds such trees), instanced BVHs must be resident (pgpu_upload_bvh8; the BVH that holds the
- * instances may be staged), and the leaf-sharded entry points do not route instance hits yet (they refuse such contexts).
+ * instances may be staged). pgpu_trace_sharded routes instance hits (every rank must hold every prototype; result rows then
+ * carry the instance as a fifth value); the building blocks pgpu_trace_leaves / pgpu_trace_leaf_records refuse such contexts.
  * Hit records: obj = leaf object inside the INSTANCED BVH, pgpu_hits.inst = leaf object (the instance) inside the traced BVH. */
 #define PGPU_INSTANCE 0xFFFFFFFFu
 typedef struct {

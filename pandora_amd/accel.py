@@ -536,8 +536,9 @@ class Context:
         cnt = capi.Counters()
         if kind == capi.CLOSEST:
             if out is None:
-                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v", "visits")}
-            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), capi.ptr(out.get("visits")))
+                out = {k: self._alloc(rays, n, "f" if k in ("t", "u", "v") else "u") for k in ("t", "obj", "leaf", "u", "v", "visits") + (("inst",) if self.instanced else ())}
+            h = capi.Hits(capi.ptr(out["t"]), capi.ptr(out["obj"]), capi.ptr(out["leaf"]), capi.ptr(out["u"]), capi.ptr(out["v"]), capi.ptr(out.get("visits")),
+                          capi.ptr(out.get("inst")))
             _check(self._L.pgpu_trace_sharded(self._h, kind, tri_mode, C.byref(r), n, C.byref(h), None, C.byref(cnt), stream), self._h)
         else:
             if out is None:
@@ -746,13 +747,22 @@ class InstancedTwoLevelScene:
     def n_leaves(self) -> int:
         return len(self.bvhs)
 
-    def upload(self, ctx: "Context", streamed: bool = False):
+    def upload(self, ctx: "Context", streamed: bool = False, resident=None):
         """Prototypes are uploaded resident (they are shared by every batching point); the batching points' own BVHs are
-        uploaded, or staged in host memory when `streamed`. Returns bvh ids per batching point (input order)."""
+        uploaded, or staged in host memory when `streamed`. Returns bvh ids per batching point (input order).
+        resident: optional bool array over leaf slots (batching points sharded over several GPUs): only those points' BVHs
+        are uploaded here, the others are NO_BVH; every rank holds all prototypes."""
         mesh_id = ctx.upload_mesh(self.pos, self.idx)
         proto_ids = [ctx.upload_bvh8(b, ctx.upload_mesh(p, i)) for b, (p, i) in zip(self.proto_bvhs, self.protos)]
+        slot_of = None
+        if resident is not None:
+            slot_of = np.empty(self.n_leaves, np.int64)
+            slot_of[np.asarray(self.top.leaf_order, np.int64)] = np.arange(self.n_leaves)
         ids = []
         for g, bvh in enumerate(self.bvhs):
+            if resident is not None and not bool(resident[slot_of[g]]):
+                ids.append(capi.NO_BVH)
+                continue
             tris, insts = self.group_tris[g], self.group_insts[g]
             objs = np.empty((tris.size + insts.size, 2), np.uint32)
             objs[:tris.size, 0] = mesh_id

@@ -132,7 +132,8 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& ar
 // ray group of every block needs (the caller provides the memory).
 void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
 int initStaticScratch(pgpu_ctx* c); // noalloc.hip
-int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream); // route_abi.hip
+// route_abi.hip. instRows: closest-hit result rows have five values (the instance of the hit last), see launchPackResults
+int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows = false);
 void destroyComm(pgpu_ctx* c); // sharded_abi.hip
 }
 

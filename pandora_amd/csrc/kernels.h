@@ -178,10 +178,11 @@ hipError_t launchRouteScatter(const float* const rays[8], const uint32_t* active
     uint32_t blocks, hipStream_t stream);
 hipError_t launchUnpackRecords(const float* records, uint32_t k, float* soa, uint32_t* workLeaf, float* t, uint32_t* obj, uint32_t* anyHit,
     uint32_t blocks, hipStream_t stream);
+// (inst != nullptr / rowFloats == 5: closest-hit rows carry the instance a hit went through as a fifth value)
 hipError_t launchPackResults(uint32_t k, const float* t, const uint32_t* obj, const float* u, const float* v, const uint32_t* anyHit, float* results,
-    uint32_t blocks, hipStream_t stream);
+    uint32_t blocks, hipStream_t stream, const uint32_t* inst = nullptr);
 hipError_t launchMergeResults(uint32_t k, const float* results, const uint32_t* sentSlot, const uint32_t* sentLeaf, float* t, uint32_t* obj,
-    uint32_t* leaf, float* u, float* v, uint32_t* anyHit, uint32_t blocks, hipStream_t stream);
+    uint32_t* leaf, float* u, float* v, uint32_t* anyHit, uint32_t blocks, hipStream_t stream, uint32_t* inst = nullptr, uint32_t rowFloats = 4);
 hipError_t launchKeyCount(const uint32_t* keys, uint32_t n, uint32_t nKeys, uint32_t* counts, uint32_t blocks, hipStream_t stream);
 
 size_t bvh8TraceLdsBytes(uint32_t stackEntries, uint32_t lanesPerRay);

@@ -15,7 +15,7 @@ namespace pandora_hip {
 
 // The owner side of one round: k received records through the batching points they name -> k results, same order.
 // (Arguments are validated by the callers.)
-int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream)
+int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows)
 {
     // scratch: SoA rays 8k, t/u/v 3k, obj/leaf/any 3k, workLeaf, sorted workRay/workBvh/workLeaf 3k, per-leaf count/start/fill, total
     const size_t nl = c->top.n_leaves;
@@ -26,7 +26,7 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
         return at;
     };
     const size_t oSoa = carve(k * 32), oT = carve(k * 4), oU = carve(k * 4), oV = carve(k * 4), oObj = carve(k * 4), oLeaf = carve(k * 4), oAny = carve(k * 4);
-    const size_t oWl = carve(k * 4), oSr = carve(k * 4), oSb = carve(k * 4), oSl = carve(k * 4);
+    const size_t oWl = carve(k * 4), oSr = carve(k * 4), oSb = carve(k * 4), oSl = carve(k * 4), oInst = carve(k * 4);
     const size_t oCnt = carve(nl * 4), oStart = carve(nl * 4), oFill = carve(nl * 4), oTotal = carve(256);
     int rc = ensure(c, c->routeWork, off);
     if (rc != PGPU_OK)
@@ -36,7 +36,7 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
     float *t = reinterpret_cast<float*>(wb + oT), *u = reinterpret_cast<float*>(wb + oU), *v = reinterpret_cast<float*>(wb + oV);
     uint32_t *obj = reinterpret_cast<uint32_t*>(wb + oObj), *leaf = reinterpret_cast<uint32_t*>(wb + oLeaf), *any = reinterpret_cast<uint32_t*>(wb + oAny);
     uint32_t *wl = reinterpret_cast<uint32_t*>(wb + oWl), *sr = reinterpret_cast<uint32_t*>(wb + oSr), *sb = reinterpret_cast<uint32_t*>(wb + oSb),
-             *sl = reinterpret_cast<uint32_t*>(wb + oSl);
+             *sl = reinterpret_cast<uint32_t*>(wb + oSl), *inst = reinterpret_cast<uint32_t*>(wb + oInst);
     uint32_t *cnt = reinterpret_cast<uint32_t*>(wb + oCnt), *start = reinterpret_cast<uint32_t*>(wb + oStart), *fill = reinterpret_cast<uint32_t*>(wb + oFill),
              *total = reinterpret_cast<uint32_t*>(wb + oTotal);
     {
@@ -71,6 +71,10 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
     ba.u_out = u;
     ba.v_out = v;
     ba.any_out = any;
+    if (instRows && closest) {
+        ba.inst_out = inst; // (written by hits only: a miss row's value is never read)
+        HIP_TRY(c, hipMemsetAsync(inst, 0xFF, k * 4, stream));
+    }
     ba.cursor = c->cursor;
     ba.chunk = c->chunk;
     ba.init_miss = 0;
@@ -87,7 +91,7 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
     if (rc != PGPU_OK)
         return rc;
     HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, nBlocks, stream));
-    HIP_TRY(c, launchPackResults(uint32_t(k), t, obj, u, v, closest ? nullptr : any, results, blocks, stream));
+    HIP_TRY(c, launchPackResults(uint32_t(k), t, obj, u, v, closest ? nullptr : any, results, blocks, stream, instRows && closest ? inst : nullptr));
     return PGPU_OK;
 }
 

@@ -152,12 +152,21 @@ __global__ __launch_bounds__(256) void unpackRecordsKernel(const float* __restri
     }
 }
 
+// result rows: {hit} (any hit), {t, obj, u, v} (closest hit), or {t, obj, u, v, inst} when the scene has instanced leaves
 __global__ __launch_bounds__(256) void packResultsKernel(uint32_t k, const float* __restrict__ t, const uint32_t* __restrict__ obj,
-    const float* __restrict__ u, const float* __restrict__ v, const uint32_t* __restrict__ anyHit, float* __restrict__ results)
+    const float* __restrict__ u, const float* __restrict__ v, const uint32_t* __restrict__ anyHit, const uint32_t* __restrict__ inst,
+    float* __restrict__ results)
 {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < k; i += gridDim.x * 256u) {
         if (anyHit) {
             results[i] = __uint_as_float(anyHit[i]);
+        } else if (inst) {
+            float* r = results + size_t(i) * 5u;
+            r[0] = t[i];
+            r[1] = __uint_as_float(obj[i]);
+            r[2] = u[i];
+            r[3] = v[i];
+            r[4] = __uint_as_float(inst[i]);
         } else {
             float4 r;
             r.x = t[i];
@@ -172,13 +181,24 @@ __global__ __launch_bounds__(256) void packResultsKernel(uint32_t k, const float
 // home side: a returned result that found something closer replaces the ray's hit record
 __global__ __launch_bounds__(256) void mergeResultsKernel(uint32_t k, const float* __restrict__ results, const uint32_t* __restrict__ sentSlot,
     const uint32_t* __restrict__ sentLeaf, float* __restrict__ t, uint32_t* __restrict__ obj, uint32_t* __restrict__ leaf, float* __restrict__ u,
-    float* __restrict__ v, uint32_t* __restrict__ anyHit)
+    float* __restrict__ v, uint32_t* __restrict__ anyHit, uint32_t* __restrict__ inst, uint32_t rowFloats)
 {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < k; i += gridDim.x * 256u) {
         const uint32_t ray = sentSlot[i];
         if (anyHit) {
             if (__float_as_uint(results[i]) != 0u)
                 anyHit[ray] = 1u;
+        } else if (rowFloats == 5u) {
+            const float* r = results + size_t(i) * 5u;
+            if (__float_as_uint(r[1]) != PGPU_MISS_ID) {
+                t[ray] = r[0];
+                obj[ray] = __float_as_uint(r[1]);
+                leaf[ray] = sentLeaf[i];
+                u[ray] = r[2];
+                v[ray] = r[3];
+                if (inst)
+                    inst[ray] = __float_as_uint(r[4]);
+            }
         } else {
             const float4 r = reinterpret_cast<const float4*>(results)[i];
             if (__float_as_uint(r.y) != PGPU_MISS_ID) {
@@ -256,16 +276,16 @@ hipError_t launchUnpackRecords(const float* records, uint32_t k, float* soa, uin
 }
 
 hipError_t launchPackResults(uint32_t k, const float* t, const uint32_t* obj, const float* u, const float* v, const uint32_t* anyHit, float* results,
-    uint32_t blocks, hipStream_t stream)
+    uint32_t blocks, hipStream_t stream, const uint32_t* inst)
 {
-    hipLaunchKernelGGL(packResultsKernel, dim3(blocks), dim3(256), 0, stream, k, t, obj, u, v, anyHit, results);
+    hipLaunchKernelGGL(packResultsKernel, dim3(blocks), dim3(256), 0, stream, k, t, obj, u, v, anyHit, inst, results);
     return hipGetLastError();
 }
 
 hipError_t launchMergeResults(uint32_t k, const float* results, const uint32_t* sentSlot, const uint32_t* sentLeaf, float* t, uint32_t* obj,
-    uint32_t* leaf, float* u, float* v, uint32_t* anyHit, uint32_t blocks, hipStream_t stream)
+    uint32_t* leaf, float* u, float* v, uint32_t* anyHit, uint32_t blocks, hipStream_t stream, uint32_t* inst, uint32_t rowFloats)
 {
-    hipLaunchKernelGGL(mergeResultsKernel, dim3(blocks), dim3(256), 0, stream, k, results, sentSlot, sentLeaf, t, obj, leaf, u, v, anyHit);
+    hipLaunchKernelGGL(mergeResultsKernel, dim3(blocks), dim3(256), 0, stream, k, results, sentSlot, sentLeaf, t, obj, leaf, u, v, anyHit, inst, rowFloats);
     return hipGetLastError();
 }
 

@@ -361,8 +361,6 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: no owner table for this top level (pgpu_set_leaf_owners)");
     if (c->nStaged > 0)
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
-    if (c->hasInstances)
-        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: this context holds instanced BVHs; instance hits are not routed between ranks yet");
     if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_sharded: kind must be PGPU_CLOSEST or PGPU_ANY");
     if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
@@ -401,11 +399,11 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     const size_t oNode = carve(nb * 4), oStack = carve(nb * 8), oParked = carve(nb * 4), oWorkA = carve(nb * 4), oWorkB = carve(nb * 4);
     const size_t oWorkBvh = carve(nb * 4), oWorkLeaf = carve(nb * 4), oSlot = carve(nb * 4), oSentLeaf = carve(nb * 4);
     const size_t oLeafCount = carve(nl * 4), oLeafStart = carve(nl * 4), oLeafFill = carve(nl * 4), oTotal = carve(256);
-    const size_t oCounts = carve(256), oFill = carve(256), oMatrix = carve(size_t(world) * world * 4);
+    const size_t oCounts = carve(512), oFill = carve(256), oMatrix = carve(size_t(world) * (world + 1u) * 4);
     rc = ensure(c, c->shardWork, off);
     if (rc != PGPU_OK)
         return rc;
-    rc = ensure(c, c->shardSend, alignUp(nb * 36) + alignUp(nb * 16)); // records out, results back
+    rc = ensure(c, c->shardSend, alignUp(nb * 36) + alignUp(nb * 20)); // records out, results back (20 bytes each with instances)
     if (rc != PGPU_OK)
         return rc;
     unsigned char* wb = static_cast<unsigned char*>(c->shardWork.ptr);
@@ -428,6 +426,9 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     float* dResBack = reinterpret_cast<float*>(static_cast<unsigned char*>(c->shardSend.ptr) + alignUp(nb * 36));
 
     uint32_t* dVisits = hits ? hits->visits : nullptr;
+    uint32_t* dInst = closest ? hits->inst : nullptr;
+    if (dInst && n)
+        HIP_TRY(c, hipMemsetAsync(dInst, 0xFF, n * 4, stream)); // a hit through an instance overwrites it, a later plain hit resets it
     HIP_TRY(c, hipMemsetAsync(c->topCounters, 0, 64, stream));
     if (c->stats)
         HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
@@ -475,6 +476,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         ba.leaf_out = hits->leaf;
         ba.u_out = hits->u;
         ba.v_out = hits->v;
+        ba.inst_out = dInst;
     }
     ba.any_out = any_hit;
     ba.cursor = c->cursor;
@@ -484,17 +486,21 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
 
     const uint32_t topPerCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
     const uint32_t topMaxBlocks = uint32_t(c->numCUs) * topPerCU;
-    std::vector<uint32_t> matrix(size_t(world) * world, 0u), sendCounts(world), recvCounts(world), starts(64, 0u);
+    std::vector<uint32_t> matrix(size_t(world) * world, 0u), gathered(size_t(world) * (world + 1u), 0u), sendCounts(world), recvCounts(world), starts(64, 0u);
     uint64_t rounds = 0, leafVisits = 0, routed = 0, exchangeBytes = 0;
     uint32_t nActive = uint32_t(n);
     const uint32_t* active = nullptr; // round 0: every ray, identity order
     int flip = 0;
-    const size_t resultBytes = closest ? 16 : 4;
+    // Result rows: {hit}, {t, obj, u, v}, or with a fifth value -- the instance a hit went through -- when any rank of the job
+    // holds instanced leaves. Every rank must use the same row size: the flag travels with the first round's count matrix.
+    size_t resultBytes = closest ? 16 : 4;
+    bool instRows = false;
     // a record carries the ray with tfar = its current t (closest hit), so the owner only reports something closer
     const float* recordSrc[8] = { rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], closest ? hits->t : rp[7] };
     for (;;) {
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
-        HIP_TRY(c, hipMemsetAsync(dCounts, 0, 512, stream)); // counts and fill sit 256 bytes apart
+        HIP_TRY(c, hipMemsetAsync(dCounts, 0, 512, stream)); // counts per owner, then this rank's "holds instances" flag
+        HIP_TRY(c, hipMemsetAsync(dFill, 0, 256, stream));
         uint32_t* const workOut = dWork[flip];
         if (nActive) {
             ta.active = active;
@@ -507,18 +513,25 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
             HIP_TRY(c, launchRouteCount(dParked, nActive, c->leafOwnerDev, uint32_t(nl), world, dCounts, gridFor(c, nActive), stream));
         }
         // the one host synchronisation of the round: who sends how many records to whom (row r = rank r's counts per owner;
-        // the diagonal counts the rays that parked at their own rank's points)
+        // the diagonal counts the rays that parked at their own rank's points; behind each row: does that rank hold instances?)
+        const uint32_t hasInst = c->hasInstances ? 1u : 0u;
+        HIP_TRY(c, hipMemcpyAsync(dCounts + world, &hasInst, 4, hipMemcpyHostToDevice, stream));
         if (world > 1) {
-            if (c->comm->transport.allgather_u32(c->comm->transport.user, dCounts, dMatrix, world, stream) != 0)
+            if (c->comm->transport.allgather_u32(c->comm->transport.user, dCounts, dMatrix, world + 1u, stream) != 0)
                 return transportFail(c, "pgpu_trace_sharded: all-gather of the record counts failed");
-            HIP_TRY(c, hipMemcpyAsync(matrix.data(), dMatrix, matrix.size() * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipMemcpyAsync(gathered.data(), dMatrix, gathered.size() * 4, hipMemcpyDeviceToHost, stream));
         } else {
-            HIP_TRY(c, hipMemcpyAsync(matrix.data(), dCounts, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipMemcpyAsync(gathered.data(), dCounts, 8, hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(c, hipStreamSynchronize(stream));
         uint64_t total = 0;
-        for (uint32_t v : matrix)
-            total += v;
+        for (uint32_t r = 0; r < world; ++r) {
+            for (uint32_t p = 0; p < world; ++p)
+                total += matrix[size_t(r) * world + p] = gathered[size_t(r) * (world + 1u) + p];
+            instRows = instRows || gathered[size_t(r) * (world + 1u) + world] != 0u;
+        }
+        if (closest)
+            resultBytes = instRows ? 20 : 16;
         if (total == 0)
             break;
         ++rounds;
@@ -550,7 +563,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
             if (sendTotal)
                 HIP_TRY(c, launchRouteScatter(recordSrc, active, dParked, nActive, c->leafOwnerRemoteDev, uint32_t(nl), world, starts.data(), dFill, dSendRec, dSlot,
                                dSentLeaf, gridFor(c, nActive), stream));
-            rc = ensure(c, c->shardRecv, alignUp(size_t(std::max(recvTotal, 1u)) * 36) + alignUp(size_t(std::max(recvTotal, 1u)) * 16));
+            rc = ensure(c, c->shardRecv, alignUp(size_t(std::max(recvTotal, 1u)) * 36) + alignUp(size_t(std::max(recvTotal, 1u)) * 20));
             if (rc != PGPU_OK)
                 return rc;
             float* dRecvRec = static_cast<float*>(c->shardRecv.ptr);
@@ -559,7 +572,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
             if (c->comm->transport.exchange(c->comm->transport.user, dSendRec, sendCounts.data(), dRecvRec, recvCounts.data(), 36, stream) != 0)
                 return transportFail(c, "pgpu_trace_sharded: record exchange failed");
             if (recvTotal) {
-                rc = traceLeafRecords(c, kind, tri_mode, dRecvRec, recvTotal, dResOut, stream);
+                rc = traceLeafRecords(c, kind, tri_mode, dRecvRec, recvTotal, dResOut, stream, instRows);
                 if (rc != PGPU_OK)
                     return rc;
             }
@@ -568,7 +581,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
             if (sendTotal)
                 HIP_TRY(c, launchMergeResults(sendTotal, dResBack, dSlot, dSentLeaf, closest ? hits->t : nullptr, closest ? hits->obj : nullptr,
                                closest ? hits->leaf : nullptr, closest ? hits->u : nullptr, closest ? hits->v : nullptr, closest ? nullptr : any_hit,
-                               gridFor(c, sendTotal), stream));
+                               gridFor(c, sendTotal), stream, dInst, closest && instRows ? 5u : 4u));
             exchangeBytes += (uint64_t(sendTotal) + recvTotal) * (36 + resultBytes);
         }
         active = workOut;

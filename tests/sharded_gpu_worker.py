@@ -15,12 +15,16 @@ from pandora_amd import sharded  # noqa: E402
 
 
 def main():
-    out_dir, kind, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])  # mode 0 / 1: Python loop (torch / device records), 2: pgpu_trace_sharded
+    # mode 0 / 1: Python loop (torch / device records), 2: pgpu_trace_sharded, 3: pgpu_trace_sharded on the instanced landscape
+    out_dir, kind, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     device_records = bool(mode)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda", 0)
+        if mode == 3:
+            instanced_landscape(out_dir, kind, rank, world, dev)
+            return
         mesh = pa.scenes.g_small()
         tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=32)
         owner_by_input = sharded.assign_leaves([b.n_nodes for b in tl.bvhs], world)
@@ -49,6 +53,28 @@ def main():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def landscape_scene():
+    terrain, protos, proto, mats = pa.scenes.g_landscape(n_prototypes=6, n_instances=500, terrain_n=64, size=80.0, detail=2)
+    return pa.accel.build_instanced_two_level(terrain.pos, terrain.idx, [(p.pos, p.idx) for p in protos], proto, mats, 1500, svdag_res=32)
+
+
+def instanced_landscape(out_dir, kind, rank, world, dev):
+    """Batching points (terrain triangles + tree instances) alternate between the ranks; every rank holds all prototypes. A ray
+    that parks at the other rank's point travels there, may hit a tree through its instance, and the instance id comes back."""
+    tl = landscape_scene()
+    owner = (np.arange(tl.n_leaves) % world).astype(np.uint32)  # per leaf slot
+    ctx = pa.accel.Context(0)
+    tl.upload(ctx, resident=(owner == rank))
+    rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
+    d_rays = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)
+    sharded.comm_init(ctx, dev, host_staged=True)
+    ctx.set_leaf_owners(owner)
+    st, cnt = ctx.trace_sharded(d_rays, kind=kind)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), routed=cnt["records_routed"], rounds=cnt["rounds"], leaf_visits=cnt["leaf_visits"],
+             svdag_tests=cnt["svdag_tests"], svdag_culled=cnt["svdag_culled"], **{k: v.cpu().numpy() for k, v in st.items()})
+    ctx.close()
 
 
 if __name__ == "__main__":

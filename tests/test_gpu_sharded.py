@@ -138,3 +138,48 @@ def test_two_processes_sharded_leaves(scene, kind, device_records):
     assert sum(int(p["leaf_visits"]) for p in parts) == wcnt["leaf_visits"]
     assert sum(int(p["svdag_tests"]) for p in parts) == wcnt["svdag_tests"]
     assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
+
+
+@pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
+def test_two_processes_sharded_instanced_landscape(kind):
+    """Instanced leaves + batching points sharded over two ranks (pgpu_trace_sharded): the instancing BVHs live on their owners,
+    the prototypes on both; results -- the instance a hit went through included, which travels back as a fifth value of the
+    result row -- equal one context's pgpu_trace, which tests/test_gpu_instances.py checks against the oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import sharded_gpu_worker as worker
+    tl = worker.landscape_scene()
+    size = 80.0
+    rays = np.ascontiguousarray(np.concatenate([
+        pa.scenes.primary_rays((0.1 * size, 25.0, 0.1 * size), (0.6 * size, 0.0, 0.6 * size), (0, 1, 0), 55, 64, 64),
+        pa.scenes.random_rays((0, 0, 0), (size, 20, size), 4000, seed=21)], axis=1))
+    ctx = pa.accel.Context(0)
+    try:
+        tl.upload(ctx)
+        want, wcnt = ctx.trace(rays, kind=kind)
+    finally:
+        ctx.close()
+    if kind == pa.capi.CLOSEST:
+        assert (want["inst"] != 0xFFFFFFFF).mean() > 0.02, "the rays should meet some trees"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "rays.npy"), rays)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(kind), "3"], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+        parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(2)]
+    assert sum(int(p["routed"]) for p in parts) > 0
+    keys = ("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits", "inst")
+    for r, p in enumerate(parts):
+        for k in keys:
+            bad = np.nonzero(_bits(p[k]) != _bits(want[k])[r::2])[0]
+            assert bad.size == 0, f"rank {r}: {k} differs on {bad.size} rays, first {bad[:6]}"
+    assert sum(int(p["leaf_visits"]) for p in parts) == wcnt["leaf_visits"]
+    assert sum(int(p["svdag_tests"]) for p in parts) == wcnt["svdag_tests"]
