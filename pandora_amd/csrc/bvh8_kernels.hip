@@ -867,13 +867,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                 const Bvh8Dev bd = a.bvhs[min(bvhId, a.n_bvhs - 1u)];
                 nodesP = bd.nodes + p * 16u;
                 trisP = bd.tris + p * 96u;
-                ox = a.ox[rayId];
-                oy = a.oy[rayId];
-                oz = a.oz[rayId];
-                dx = a.dx[rayId];
-                dy = a.dy[rayId];
-                dz = a.dz[rayId];
-                tnear = a.tnear[rayId];
+                if (a.ray_aos) {
+                    const float4 o = a.ray_aos[2u * size_t(rayId)], d = a.ray_aos[2u * size_t(rayId) + 1u];
+                    ox = o.x;
+                    oy = o.y;
+                    oz = o.z;
+                    tnear = o.w;
+                    dx = d.x;
+                    dy = d.y;
+                    dz = d.z;
+                } else {
+                    ox = a.ox[rayId];
+                    oy = a.oy[rayId];
+                    oz = a.oz[rayId];
+                    dx = a.dx[rayId];
+                    dy = a.dy[rayId];
+                    dz = a.dz[rayId];
+                    tnear = a.tnear[rayId];
+                }
                 tfar = a.tfar_in[rayId];
                 ix = 1.0f / dx; // wive_bvh8_impl.h:66-68: no zero guard
                 iy = 1.0f / dy;
@@ -1197,8 +1208,8 @@ size_t bvh8TraceLdsBytes(uint32_t stackEntries, uint32_t lanesPerRay)
 hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
 {
     const dim3 grid(blocks), block(256);
-    if (args.n_work_dev && (args.lanes_per_ray != 2u || args.instanced))
-        return hipErrorInvalidValue; // (only the pair-layout kernel reads its list length from device memory)
+    if ((args.n_work_dev || args.ray_aos) && (args.lanes_per_ray != 2u || args.instanced))
+        return hipErrorInvalidValue; // (only the pair-layout kernel reads its list length from device memory / rays as records)
     const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries, args.lanes_per_ray);
 #define PANDORA_LAUNCH(ANYV, TRIV, STATV)                                                                            \
     do {                                                                                                             \

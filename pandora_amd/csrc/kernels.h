@@ -48,6 +48,10 @@ struct Bvh8TraceArgs {
     uint32_t fixed_bvh;
     uint32_t n_bvhs;   // work items naming a bvh id beyond this are skipped (geometry not resident here)
     uint32_t n_work;
+    // optional, pair layout only: the rays as 32-byte records {ox, oy, oz, tnear}{dx, dy, dz, tfar} by ray id (written by the
+    // top-level kernel's first episode). A work list sorted by batching point visits ray ids in random order: the eight arrays
+    // cost eight memory sectors per ray, the record one. tfar is still read from tfar_in (it is the ray's current t there).
+    const float4* ray_aos;
     const uint32_t* n_work_dev; // optional, pair layout only: the real number of work items (<= n_work, which then only sizes the launch)
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
     float* t_out;
@@ -108,6 +112,10 @@ struct TopTraceArgs {
     const uint32_t* active; // ray ids to advance (nullptr: identity)
     uint32_t n_active;
     const uint32_t* n_active_dev; // optional: the real number of work items (<= n_active, which then only sizes the launch)
+    // the rays as 32-byte records by ray id (see Bvh8TraceArgs::ray_aos): read from ray_aos when set, else from the eight arrays;
+    // ray_aos_out (the first episode of a trace, whose list is the identity): every ray that is read is also written as a record
+    const float4* ray_aos;
+    float4* ray_aos_out;
     const float *ox, *oy, *oz, *dx, *dy, *dz, *tnear, *tfar_in;
     const float* tfar_state; // closest-hit: current ray.tfar
     uint32_t* node;          // PauseableBVHInsertHandle.first  (pauseable_bvh.h:8)
@@ -165,6 +173,10 @@ hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill
 hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream,
     bool requests = false, const uint32_t* nActiveDev = nullptr);
+// nextActive = the entries of `active` (nullptr: identity) whose parkedLeaf names a batching point, in order; `slices` (<= 4096)
+// fixed slices of the list are counted, scanned (sliceCount / sliceStart / scratchFill: `slices` words each) and written
+hipError_t launchCompactParked(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t n, const uint32_t* nDev, uint32_t nLeaves, uint32_t* sliceCount,
+    uint32_t* sliceStart, uint32_t* scratchFill, uint32_t* scratchTotal, uint32_t* nextActive, uint32_t slices, hipStream_t stream);
 hipError_t launchLeafToBvh(const uint32_t* workLeaf, const TopLeafDev* leaves, uint32_t nLeaves, uint32_t* workBvh, uint32_t n, uint32_t blocks, hipStream_t stream);
 hipError_t launchInitState(uint32_t n, uint32_t root, uint32_t* node, uint64_t* stack, const float* tfarIn, float* tState, uint32_t* obj,
     uint32_t* leaf, float* u, float* v, uint32_t* visits, uint32_t* anyOut, uint32_t blocks, hipStream_t stream);

@@ -343,6 +343,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     const size_t oWorkRay = carve(n * 4), oWorkBvh = carve(n * 4), oWorkLeaf = carve(n * 4);
     const size_t oLeafCount = carve(nl * 4), oLeafStart = carve(nl * 4), oLeafFill = carve(nl * 4);
     const size_t oParkedCount = carve(256), oCounters = carve(256);
+    const size_t oRayAos = carve(n * 32);
+    const size_t oIdsA = carve(n * 4), oIdsB = carve(n * 4), oSliceCount = carve(4096 * 4), oSliceStart = carve(4096 * 4), oSliceFill = carve(4096 * 4);
     // deferred casts: the requests sorted by batching point, and per point their count / first / fill + the total
     const size_t oReqList = carve(n * 4), oReqCount = carve(nl * 4), oReqStart = carve(nl * 4), oReqFill = carve(nl * 4), oUnitStart = carve(nl * 4), oReqTotal = carve(256);
     size_t oRays = 0, oHits = 0;
@@ -365,6 +367,11 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     uint32_t* dLeafStart = reinterpret_cast<uint32_t*>(wb + oLeafStart);
     uint32_t* dLeafFill = reinterpret_cast<uint32_t*>(wb + oLeafFill);
     uint32_t* dParkedCount = reinterpret_cast<uint32_t*>(wb + oParkedCount);
+    uint32_t* dIds[2] = { reinterpret_cast<uint32_t*>(wb + oIdsA), reinterpret_cast<uint32_t*>(wb + oIdsB) }; // the top level's lists, by ray id
+    float4* dRayAos = reinterpret_cast<float4*>(wb + oRayAos);
+    uint32_t* dSliceCount = reinterpret_cast<uint32_t*>(wb + oSliceCount);
+    uint32_t* dSliceStart = reinterpret_cast<uint32_t*>(wb + oSliceStart);
+    uint32_t* dSliceFill = reinterpret_cast<uint32_t*>(wb + oSliceFill);
     unsigned long long* dCounters = reinterpret_cast<unsigned long long*>(wb + oCounters);
     uint32_t* dReqList = reinterpret_cast<uint32_t*>(wb + oReqList);
     uint32_t* dReqCount = reinterpret_cast<uint32_t*>(wb + oReqCount);
@@ -525,14 +532,29 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ta.active = active;
             ta.n_active = bound;
             ta.n_active_dev = countIn;
+            // the first episode reads the rays from the caller's arrays (its list is the identity: coalesced) and leaves them behind
+            // as 32-byte records; everything after it -- lists in batching-point order -- reads one sector per ray instead of eight
+            ta.ray_aos = r ? dRayAos : nullptr;
+            ta.ray_aos_out = r ? nullptr : dRayAos;
+            ba.ray_aos = dRayAos;
             ta.may_park = r < nl ? 1u : 0u; // a ray pauses at most once per batching point
             ta.only_culled = 0u;
             const uint32_t listBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (bound + 255u) / 256u));
             HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (bound + 255u) / 256u)), stream));
             HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), countOut, stream));
+            // The parked rays by batching point, for the bottom level (binning). The next top-level episode takes the same list when
+            // its waves run in lockstep -- rays of one batching point walk the same nodes and cast through the same DAG -- and the
+            // parked rays in the order of the current list, i.e. by ascending ray id, when its lanes are independent anyway
+            // (launchCompactParked): coalesced reads are then worth more than coherent waves.
             uint32_t* const workRayOut = (active == dWorkRay) ? dWorkRayAlt : dWorkRay;
             HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, bound, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
                            listBlocks, stream, false, countIn));
+            uint32_t* nextActive = workRayOut;
+            if (ta.lanes_refill_min != 0u) {
+                nextActive = dIds[r & 1u];
+                HIP_TRY(c, launchCompactParked(active, dParkedLeaf, bound, countIn, uint32_t(nl), dSliceCount, dSliceStart, dSliceFill, dParkedCount + 8,
+                               nextActive, std::max(1u, std::min(4096u, (bound + 1023u) / 1024u)), stream));
+            }
             HIP_TRY(c, hipMemcpyAsync(&c->roundCounts[r], countOut, 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipEventRecord(c->roundEv[r & 1u], stream));
             HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
@@ -545,7 +567,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             if (rc != PGPU_OK)
                 return rc;
             HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
-            active = workRayOut;
+            active = nextActive;
             if (r >= 1) {
                 HIP_TRY(c, hipEventSynchronize(c->roundEv[(r - 1) & 1u]));
                 const uint32_t parked = c->roundCounts[r - 1];

@@ -254,6 +254,50 @@ __device__ __forceinline__ KeyGroup groupByKey(uint32_t key, bool active)
     return kg;
 }
 
+// the ray of an episode: from its 32-byte record when the trace keeps them (TopTraceArgs::ray_aos), else from the eight arrays
+// -- and then also copied into a record when the trace wants them made (ray_aos_out)
+__device__ __forceinline__ void loadRay(const TopTraceArgs& a, uint32_t ray, float& ox, float& oy, float& oz, float& dx, float& dy, float& dz, float& tnear)
+{
+    if (a.ray_aos) {
+        const float4 o = a.ray_aos[2u * size_t(ray)], d = a.ray_aos[2u * size_t(ray) + 1u];
+        ox = o.x;
+        oy = o.y;
+        oz = o.z;
+        tnear = o.w;
+        dx = d.x;
+        dy = d.y;
+        dz = d.z;
+        return;
+    }
+    ox = a.ox[ray];
+    oy = a.oy[ray];
+    oz = a.oz[ray];
+    dx = a.dx[ray];
+    dy = a.dy[ray];
+    dz = a.dz[ray];
+    tnear = a.tnear[ray];
+    // (written here, while the values are in hand: writing only the rays that park -- the only ones anybody reads again -- at the
+    // end of the episode keeps seven more values alive through the traversal and was slower, 6.77 against 6.67 ms per step.
+    // The fourth value of the second half is never read: the kernels take tfar from the state arrays.)
+    if (a.ray_aos_out) {
+        a.ray_aos_out[2u * size_t(ray)] = make_float4(ox, oy, oz, tnear);
+        a.ray_aos_out[2u * size_t(ray) + 1u] = make_float4(dx, dy, dz, 0.0f);
+    }
+}
+__device__ __forceinline__ void loadDirection(const TopTraceArgs& a, uint32_t ray, float& dx, float& dy, float& dz)
+{
+    if (a.ray_aos) {
+        const float4 d = a.ray_aos[2u * size_t(ray) + 1u];
+        dx = d.x;
+        dy = d.y;
+        dz = d.z;
+        return;
+    }
+    dx = a.dx[ray];
+    dy = a.dy[ray];
+    dz = a.dz[ray];
+}
+
 template <bool ANY, bool NODES_IN_LDS, bool DEFER>
 __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void topTraverseKernel(TopTraceArgs a)
 {
@@ -291,9 +335,8 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         uint32_t leafId = 0;
         // a shadow ray already occluded in its last leaf is done (offline_batching...h:246-247)
         if (live && !(ANY && a.any_out[ray] != 0u)) {
-            const float ox = a.ox[ray], oy = a.oy[ray], oz = a.oz[ray];
-            const float dx = a.dx[ray], dy = a.dy[ray], dz = a.dz[ray];
-            const float tnear = a.tnear[ray];
+            float ox, oy, oz, dx, dy, dz, tnear;
+            loadRay(a, ray, ox, oy, oz, dx, dy, dz, tnear);
             const float tfar = ANY ? a.tfar_in[ray] : a.tfar_state[ray]; // simdRay is rebuilt from the ray at every resume (:243-254)
             const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz; // :241
             uint32_t node = a.node[ray];
@@ -481,14 +524,12 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs
                 if (ANY && a.any_out[ray] != 0u) {
                     a.parked_leaf[w] = PGPU_MISS_ID; // a shadow ray already occluded in its last leaf is done (offline_batching...h:246-247)
                 } else {
-                    ox = a.ox[ray];
-                    oy = a.oy[ray];
-                    oz = a.oz[ray];
-                    tnear = a.tnear[ray];
+                    float dx, dy, dz;
+                    loadRay(a, ray, ox, oy, oz, dx, dy, dz, tnear);
                     tfar = ANY ? a.tfar_in[ray] : a.tfar_state[ray]; // simdRay is rebuilt from the ray at every resume (:243-254)
-                    ix = 1.0f / a.dx[ray]; // :241
-                    iy = 1.0f / a.dy[ray];
-                    iz = 1.0f / a.dz[ray];
+                    ix = 1.0f / dx; // :241
+                    iy = 1.0f / dy;
+                    iz = 1.0f / dz;
                     node = a.node[ray];
                     stack = a.stack[ray];
                     steps = 0;
@@ -541,7 +582,9 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs
                                 if (lf.svdag != PGPU_MISS_ID) {
                                     ++nTests;
                                     const SvdagDev dag = a.top.dags[lf.svdag];
-                                    const int r = castInit(cs, dagWords, dag.root, dag, ox, oy, oz, a.dx[ray], a.dy[ray], a.dz[ray]);
+                                    float dx, dy, dz;
+                                    loadDirection(a, ray, dx, dy, dz);
+                                    const int r = castInit(cs, dagWords, dag.root, dag, ox, oy, oz, dx, dy, dz);
                                     if (r == 0) {
                                         castLeaf = leaf;
                                         mode = 2;
@@ -869,6 +912,68 @@ __global__ __launch_bounds__(256) void binByLeafLdsKernel(const uint32_t* __rest
     }
 }
 
+// The next round's list for the top-level kernel: the rays that parked, in the order of the current list (an order-preserving
+// compaction). Round 0 lists the rays by id, so every later list is ascending in ray id too, and the top-level kernel -- which
+// reads twelve per-ray values through the list -- touches memory almost as coalesced as in round 0. (The bottom level needs the
+// other order, by batching point: binByLeaf writes that list. Taking it for the next top-level episode as well made that
+// kernel gather every value of every ray from a different cache line.) Two passes over fixed slices: count, then -- after a
+// scan of the slice counts -- write.
+__device__ __forceinline__ void compactSlice(uint32_t n, uint32_t& lo, uint32_t& hi)
+{
+    const uint32_t per = (((n + gridDim.x - 1u) / gridDim.x) + 255u) & ~255u;
+    lo = min(blockIdx.x * per, n);
+    hi = min(lo + per, n);
+}
+
+__global__ __launch_bounds__(256) void compactCountKernel(const uint32_t* __restrict__ parkedLeaf, uint32_t n, const uint32_t* __restrict__ nDev,
+    uint32_t nLeaves, uint32_t* __restrict__ sliceCount)
+{
+    __shared__ uint32_t waveSum[4];
+    if (nDev)
+        n = min(n, *nDev);
+    uint32_t lo, hi;
+    compactSlice(n, lo, hi);
+    uint32_t mine = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u)
+        mine += parkedLeaf[i] < nLeaves ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1)
+        mine += uint32_t(__shfl_xor(int(mine), o));
+    if ((threadIdx.x & 63u) == 0u)
+        waveSum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        sliceCount[blockIdx.x] = waveSum[0] + waveSum[1] + waveSum[2] + waveSum[3];
+}
+
+__global__ __launch_bounds__(256) void compactWriteKernel(const uint32_t* __restrict__ active, const uint32_t* __restrict__ parkedLeaf, uint32_t n,
+    const uint32_t* __restrict__ nDev, uint32_t nLeaves, const uint32_t* __restrict__ sliceStart, uint32_t* __restrict__ nextActive)
+{
+    __shared__ uint32_t waveSum[4];
+    if (nDev)
+        n = min(n, *nDev);
+    uint32_t lo, hi;
+    compactSlice(n, lo, hi);
+    uint32_t base = sliceStart[blockIdx.x];
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool live = i < hi && parkedLeaf[i] < nLeaves;
+        const uint64_t mask = __ballot(live);
+        if ((threadIdx.x & 63u) == 0u)
+            waveSum[wave] = uint32_t(__popcll(mask));
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            before += k < wave ? waveSum[k] : 0u;
+            total += waveSum[k];
+        }
+        if (live)
+            nextActive[base + before + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))] = active ? active[i] : i;
+        base += total;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void leafToBvhKernel(const uint32_t* __restrict__ workLeaf, const TopLeafDev* __restrict__ leaves, uint32_t nLeaves,
     uint32_t* __restrict__ workBvh, uint32_t n)
 {
@@ -1005,6 +1110,15 @@ hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, u
     }
     hipLaunchKernelGGL(binByLeafKernel, dim3(blocks), dim3(256), 0, stream, active, parkedLeaf, nActive, nLeaves, leafStart, leafFill, leaves,
         workRay, workBvh, workLeaf, requests, nActiveDev);
+    return hipGetLastError();
+}
+
+hipError_t launchCompactParked(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t n, const uint32_t* nDev, uint32_t nLeaves, uint32_t* sliceCount,
+    uint32_t* sliceStart, uint32_t* scratchFill, uint32_t* scratchTotal, uint32_t* nextActive, uint32_t slices, hipStream_t stream)
+{
+    hipLaunchKernelGGL(compactCountKernel, dim3(slices), dim3(256), 0, stream, parkedLeaf, n, nDev, nLeaves, sliceCount);
+    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, sliceCount, sliceStart, scratchFill, slices, scratchTotal);
+    hipLaunchKernelGGL(compactWriteKernel, dim3(slices), dim3(256), 0, stream, active, parkedLeaf, n, nDev, nLeaves, sliceStart, nextActive);
     return hipGetLastError();
 }
 
