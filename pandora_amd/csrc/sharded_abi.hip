@@ -400,6 +400,9 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     const size_t oWorkBvh = carve(nb * 4), oWorkLeaf = carve(nb * 4), oSlot = carve(nb * 4), oSentLeaf = carve(nb * 4);
     const size_t oLeafCount = carve(nl * 4), oLeafStart = carve(nl * 4), oLeafFill = carve(nl * 4), oTotal = carve(256);
     const size_t oCounts = carve(512), oFill = carve(256), oMatrix = carve(size_t(world) * (world + 1u) * 4);
+    // the rays as 32-byte records by ray id, as in pgpu_trace (Bvh8TraceArgs::ray_aos): pair-layout lists only
+    const bool rayRecords = !c->hasInstances && (c->lanesPerRay == 0u || c->lanesPerRay == 2u);
+    const size_t oRayAos = carve(rayRecords ? nb * 32 : 0);
     rc = ensure(c, c->shardWork, off);
     if (rc != PGPU_OK)
         return rc;
@@ -422,6 +425,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     uint32_t* dCounts = reinterpret_cast<uint32_t*>(wb + oCounts);
     uint32_t* dFill = reinterpret_cast<uint32_t*>(wb + oFill);
     uint32_t* dMatrix = reinterpret_cast<uint32_t*>(wb + oMatrix);
+    float4* dRayAos = rayRecords ? reinterpret_cast<float4*>(wb + oRayAos) : nullptr;
     float* dSendRec = static_cast<float*>(c->shardSend.ptr);
     float* dResBack = reinterpret_cast<float*>(static_cast<unsigned char*>(c->shardSend.ptr) + alignUp(nb * 36));
 
@@ -506,6 +510,8 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
             ta.active = active;
             ta.n_active = nActive;
             ta.may_park = rounds < nl ? 1u : 0u; // a ray pauses at most once per batching point
+            ta.ray_aos = active ? dRayAos : nullptr; // the first episode (identity list) reads the caller's arrays and writes the records
+            ta.ray_aos_out = active ? nullptr : dRayAos;
             HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u)), stream));
             HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), dTotal, stream));
             HIP_TRY(c, launchBinByLeaf(active, dParked, nActive, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workOut, dWorkBvh, dWorkLeaf,
@@ -553,6 +559,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
             ba.work_ray = workOut;
             ba.n_work = parked;
             ba.chunk = c->chunk;
+            ba.ray_aos = dRayAos;
             uint32_t blocks = 1;
             rc = planBvh8Launch(c, deepest, parked, ba, &blocks);
             if (rc != PGPU_OK)
