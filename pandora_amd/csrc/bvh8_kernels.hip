@@ -37,6 +37,11 @@ constexpr uint32_t kWavesPerBlock = 4;
 // from what lets 6 blocks share a CU. The stride is an odd number of 8-byte entries, which spreads the 16
 // stacks of a wave over the LDS banks.
 __host__ __device__ constexpr uint32_t stackStrideBytes(uint32_t entries) { return (entries * 8u) | 8u; }
+// Quad layout: the four lanes of a quad pop by reading the ray's top four entries, 32 contiguous bytes, with ds_read_b64 --
+// banked over 64 dwords per half-wave, i.e. per 8 rays. A stride of an odd number of 32-byte units puts the 8 rays' reads on
+// 8 different eighths of the bank row whenever their stack depths agree modulo 4 (88 bytes, the old stride for 11 entries, made
+// rays 0 / 3 / 6 and 1 / 4 / 7 overlap whatever the depths).
+__host__ __device__ constexpr uint32_t quadStackStrideBytes(uint32_t entries) { return (((entries * 8u + 31u) / 32u) | 1u) * 32u; }
 
 __device__ __forceinline__ float min86(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float max86(float a, float b) { return a > b ? a : b; }
@@ -261,7 +266,7 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
     lds_u8* const pairOdd = stageU + g * 64u + q * 8u + (swz ? 0u : 32u);  // arrays maxX, maxY, maxZ, permutation
     // after the bounds have been read, the 64 bytes of the ray's minX/maxX arrays hold the 8 (child, tmin) slots
     lds_u8* const orderBase = stageU + g * 64u;
-    lds_u8* const stackBase = lds + kWavesPerBlock * kStagePerWave + (wave * kRaysPerWave + g) * stackStrideBytes(W);
+    lds_u8* const stackBase = lds + kWavesPerBlock * kStagePerWave + (wave * kRaysPerWave + g) * quadStackStrideBytes(W);
     unsigned long long* const spill = a.spill ? a.spill + (size_t(blockIdx.x * kWavesPerBlock + wave) * kRaysPerWave + g) * a.spill_entries : nullptr;
     const uint32_t myPiece16 = (q ^ swz) * 16u; // the 16-byte piece (of every 64) this lane fetches
     const uint32_t qbit = 1u << q;
@@ -1202,7 +1207,7 @@ size_t bvh8TraceLdsBytes(uint32_t stackEntries, uint32_t lanesPerRay)
 {
     if (lanesPerRay == 2u)
         return kWavesPerBlock * kPairRaysPerWave * (kPairSlotBytes + stackStrideBytes(stackEntries));
-    return kWavesPerBlock * kStagePerWave + kWavesPerBlock * kRaysPerWave * stackStrideBytes(stackEntries);
+    return kWavesPerBlock * kStagePerWave + kWavesPerBlock * kRaysPerWave * quadStackStrideBytes(stackEntries);
 }
 
 hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)

@@ -207,7 +207,7 @@ inline uint32_t stackEntriesForDepth(uint32_t depth)
 // 7 blocks fit a CU; deeper entries spill to global memory.
 inline uint32_t stackWindow(uint32_t need, int requested)
 {
-    const uint32_t cap = requested > 0 ? uint32_t(requested) : 11u;
+    const uint32_t cap = requested > 0 ? uint32_t(requested) : 12u; // (12 entries = 96 bytes per ray: 7 blocks of the quad kernel fill 154 of a CU's 160 KiB)
     return need < cap ? need : cap;
 }
 // blocks of 256 threads per CU: requested, or (0) as many as LDS (160 KiB) and registers allow
