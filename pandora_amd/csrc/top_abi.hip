@@ -580,11 +580,20 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         }
         nActive = 0; // (skips the loop below)
     }
+    bool firstEpisode = true;
     while (nActive > 0) {
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
         ta.active = active;
         ta.n_active = nActive;
+        ta.n_active_dev = nullptr;
         ta.may_park = rounds < nl ? 1u : 0u; // a ray pauses at most once per batching point
+        // the rays as 32-byte records (see the loop above): written by the first episode, read by the later ones and by the
+        // pair-layout bottom level (streamed scenes; the deferred-cast passes of the first round read the caller's arrays)
+        ta.ray_aos = (pairLists && !firstEpisode) ? dRayAos : nullptr;
+        ta.ray_aos_out = (pairLists && firstEpisode) ? dRayAos : nullptr;
+        ba.ray_aos = pairLists ? dRayAos : nullptr;
+        ba.n_work_dev = nullptr;
+        firstEpisode = false;
         const uint32_t topBlocks = std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u));
         // pgpu_set_svdag_defer (off unless asked for: measured slower than casts inside the episode).
         // Large passes with proxy geometry: the episode stops at every batching point that has an SVDAG, the requests are binned

@@ -113,3 +113,25 @@ def test_top_level_lanes_kernel_matches_oracle(two_level, refill_min, cast_trips
     finally:
         ctx.set_top_variant(0)
         ctx.set_round_lookahead(True)
+
+
+@pytest.mark.parametrize("n", [1, 63, 256, 257, 1025])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_tiny_batches_through_the_round_loop(two_level, n, variant):
+    """Batches smaller than a block, a wave, a compaction slice: the rounds queued ahead size their launches from the previous
+    counts and must neither drop nor repeat a ray."""
+    ctx, mesh, tl, orc = two_level
+    ctx.set_ray_layout(0)
+    ctx.set_kernel_variant(0, 0, 0)
+    ctx.set_top_variant(variant)
+    try:
+        rays = np.ascontiguousarray(_ray_sets(mesh)["diffuse"][:, 100:100 + n])
+        for kind, keys in ((pa.capi.CLOSEST, ("t", "obj", "leaf", "u", "v", "visits")), (pa.capi.ANY, ("hit", "visits"))):
+            got, cnt = ctx.trace(rays, kind=kind)
+            want = orc.trace(rays, any_hit=(kind == pa.capi.ANY), lanes=3)
+            for k in keys:
+                assert np.array_equal(_bits(got[k]), _bits(want[k])), f"n={n} {k}"
+            for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                assert cnt[k] == want["counters"][k], f"n={n} counter {k}"
+    finally:
+        ctx.set_top_variant(0)
