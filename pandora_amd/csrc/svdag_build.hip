@@ -222,7 +222,6 @@ __global__ __launch_bounds__(256) void pyramidKernel(const uint16_t* __restrict_
 struct LevelView {
     const uint16_t* masks;     // this level
     const uint32_t* kidCanon;  // canonical offsets of the level below (nullptr at level 1: no inner children there)
-    const uint16_t* kidMasks;  // masks of the level below (nullptr at level 1)
     uint32_t nNodes;           // nodes of this level over all batching points
     uint32_t isRoot;           // the top level: never promoted
 };
@@ -532,7 +531,6 @@ extern "C" int pgpu_build_svdags_device(pgpu_ctx* c, const float* positions, siz
         LevelView v {};
         v.masks = dMasks[size_t(l)];
         v.kidCanon = l > 1 ? dCanon[size_t(l) - 1] : nullptr;
-        v.kidMasks = l > 1 ? dMasks[size_t(l) - 1] : nullptr;
         v.nNodes = perPoint[size_t(l)] * G;
         v.isRoot = l == depth ? 1u : 0u;
         const uint32_t blocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (v.nNodes + 255u) / 256u));
