@@ -238,7 +238,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
                   "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "the round loop (topTraverseKernel + leafScan / binByLeaf + bvh8TraceKernel, all rounds), device time between the loop's first and last event",
+                    "kernel": "the round loop (topTraverseKernel + leafScan / binByLeaf + bvh8TracePairKernel, all rounds), device time between the loop's first and last event",
                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "bytes_per_leaf_visit": 88, "scene_bytes": scene_bytes}
         return config, roofline, cpu
 
