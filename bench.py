@@ -237,7 +237,17 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "batching_points": tl.n_leaves, "triangle_test": args.tri,
                   "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        # memory-side bytes per step from rocprofv3 PMC passes of this same command (tools/pmc_two_level_traffic.py), quoted as for
+        # the single-level config: counters cannot be read from inside the timed process
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_two_level.json")
+        if args.kind == "closest" and args.tri == "moller-trumbore" and args.svdag == 64 and os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("rays_per_step") == n:
+                traffic, traffic_src = tj["traffic_bytes_per_step"], "profiles/pmc_traffic_two_level.json (" + tj["how"] + ")"
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "kernel": "the round loop (topTraverseKernel + leafScan / binByLeaf + bvh8TracePairKernel, all rounds), device time between the loop's first and last event",
                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "bytes_per_leaf_visit": 88, "scene_bytes": scene_bytes}
         return config, roofline, cpu
