@@ -90,6 +90,7 @@ struct pgpu_ctx {
     std::vector<CacheSlot> slots;
     hipStream_t copyStream = nullptr;
     hipEvent_t copyDone = nullptr;
+    std::vector<pandora_hip::SvdagDev> dagsHost; // host copy of the descriptors (for the per-point records, LeafDagDev)
     // top-level kernel (pgpu_set_top_variant): 0 automatic, 1 lockstep waves, 2 lanes refilled as their rays finish
     int topVariant = 0;
     uint32_t topRefillMin = 16, topCastTrips = 4;

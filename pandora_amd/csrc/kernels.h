@@ -87,9 +87,20 @@ struct TopLeafDev {
     uint32_t bvh;
     uint32_t svdag; // PGPU_MISS_ID: no proxy geometry
 };
+// what an episode needs to know when it arrives at a batching point, in one 32-byte record per point (leaf -> svdag id -> descriptor
+// were two dependent loads in a kernel that waits for little else)
+struct LeafDagDev {
+    uint32_t root;
+    float bmin[3];
+    float invExtent;
+    uint32_t levels;
+    uint32_t has_dag; // 0: no proxy geometry, the ray parks without a test
+    uint32_t pad;
+};
 struct TopDev {
     const unsigned char* nodes;
     const TopLeafDev* leaves;
+    const LeafDagDev* leafDags; // per batching point (rebuilt whenever the top level or the SVDAGs are uploaded)
     const uint32_t* dagWords;
     const SvdagDev* dags;
     uint32_t root, n_nodes, n_leaves, n_dags;

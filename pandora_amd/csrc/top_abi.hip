@@ -97,6 +97,34 @@ int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* c
 
 } // namespace
 
+// one record per batching point with its DAG's descriptor inlined (LeafDagDev); needs the leaves, and the DAGs they name
+static int rebuildLeafDags(pgpu_ctx* c)
+{
+    if (c->topLeavesHost.empty())
+        return PGPU_OK;
+    std::vector<LeafDagDev> ld(c->topLeavesHost.size());
+    for (size_t i = 0; i < ld.size(); ++i) {
+        LeafDagDev& r = ld[i];
+        std::memset(&r, 0, sizeof(r));
+        const uint32_t s = c->topLeavesHost[i].svdag;
+        if (s != PGPU_MISS_ID && s < c->dagsHost.size()) {
+            const SvdagDev& d = c->dagsHost[s];
+            r.root = d.root;
+            for (int a = 0; a < 3; ++a)
+                r.bmin[a] = d.bmin[a];
+            r.invExtent = d.invExtent;
+            r.levels = d.levels;
+            r.has_dag = 1u;
+        }
+    }
+    LeafDagDev* dl = nullptr;
+    const int rc = uploadOwned(c, ld.data(), ld.size(), &dl);
+    if (rc != PGPU_OK)
+        return rc;
+    c->top.leafDags = dl;
+    return PGPU_OK;
+}
+
 extern "C" {
 
 int pgpu_set_top_variant(pgpu_ctx* c, int variant, int refill_min, int cast_trips)
@@ -243,7 +271,8 @@ int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const
     c->top.dags = dd;
     c->top.n_dags = uint32_t(n_dags);
     c->top.dag_levels = levels;
-    return PGPU_OK;
+    c->dagsHost = dev;
+    return rebuildLeafDags(c);
 }
 
 int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint32_t root, const pgpu_leaf* leaves, size_t n_leaves)
@@ -290,7 +319,7 @@ int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint
     c->haveTop = true;
     c->topLeavesHost = lv;
     c->topHasRemoteLeaves = remote;
-    return PGPU_OK;
+    return rebuildLeafDags(c);
 }
 
 int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,

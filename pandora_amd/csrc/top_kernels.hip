@@ -374,17 +374,17 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                             node = nu[24] + __popc((valid & ~leafMask) & ((1u << child) - 1u));
                         } else {
                             const uint32_t leaf = nu[25] + __popc((valid & leafMask) & ((1u << child) - 1u));
-                            const TopLeafDev lf = a.top.leaves[leaf];
+                            const LeafDagDev lf = a.top.leafDags[leaf];
                             bool culled = false;
-                            if (DEFER && lf.svdag != PGPU_MISS_ID) {
+                            if (DEFER && lf.has_dag != 0u) {
                                 // the cast kernel decides: parked here, or culled and on with the traversal from this token
                                 deferred = true;
                                 leafId = leaf;
                                 break;
                             }
-                            if (lf.svdag != PGPU_MISS_ID) {
+                            if (lf.has_dag != 0u) {
                                 ++nTests;
-                                const SvdagDev dag = a.top.dags[lf.svdag];
+                                const SvdagDev dag { lf.root, { lf.bmin[0], lf.bmin[1], lf.bmin[2] }, lf.invExtent, lf.levels, 0u, 0u };
                                 if (!svdagHit(a.top.dagWords, dag, ox, oy, oz, dx, dy, dz, dagStack + threadIdx.x, kTopBlock)) {
                                     ++nCulled;
                                     culled = true;
@@ -578,10 +578,10 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs
                             } else {
                                 // BatchingPoint::intersect (offline_batching...h:269-305): the proxy geometry decides
                                 const uint32_t leaf = nu[25] + __popc((valid & leafMask) & ((1u << child) - 1u));
-                                const TopLeafDev lf = a.top.leaves[leaf];
-                                if (lf.svdag != PGPU_MISS_ID) {
+                                const LeafDagDev lf = a.top.leafDags[leaf];
+                                if (lf.has_dag != 0u) {
                                     ++nTests;
-                                    const SvdagDev dag = a.top.dags[lf.svdag];
+                                    const SvdagDev dag { lf.root, { lf.bmin[0], lf.bmin[1], lf.bmin[2] }, lf.invExtent, lf.levels, 0u, 0u };
                                     float dx, dy, dz;
                                     loadDirection(a, ray, dx, dy, dz);
                                     const int r = castInit(cs, dagWords, dag.root, dag, ox, oy, oz, dx, dy, dz);
