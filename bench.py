@@ -25,6 +25,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -55,6 +56,7 @@ def parse_args():
     ap.add_argument("--svdag", type=int, default=64, help="two-level / sharded scene: SVDAG resolution (0 = no proxy geometry, svdagRes 0 in the reference)")
     ap.add_argument("--sharded-side", type=int, default=2048, help="N > 1: primary image side per rank of the sharded record")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded record")
+    ap.add_argument("--sharded-timeout", type=int, default=420, help="seconds after which the sharded record is given up and the line printed without it")
     ap.add_argument("--force-sharded", action="store_true", help="N = 1: run the sharded record too (one rank owns every batching point; rehearsal of the N > 1 path)")
     ap.add_argument("--dry", action="store_true", help="no GPU: the ranks only meet (gloo) and reduce made-up figures; checks the launch path")
     return ap.parse_args()
@@ -396,10 +398,22 @@ def main() -> int:
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "cpu_baseline": cpu}
     ctx.close()
     if (world > 1 or args.force_sharded) and not args.no_sharded:
+        # The headline figure stands on its own: whatever happens to the sharded record -- an exception, or a rank that died and
+        # left the others waiting inside a collective -- rank 0 still prints its line (with the failure in it) and every rank leaves.
+        def give_up():
+            if rank == 0:
+                line["sharded"] = {"error": "no result after %d s (a rank failed inside a collective?)" % args.sharded_timeout}
+                emit(line)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.sharded_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             rec = run_sharded(args, pa, torch, dist, dev, rank, world)
-        except Exception as e:  # the headline figure stands on its own: report the failure instead of losing the line
+        except Exception as e:
             rec = {"error": f"{type(e).__name__}: {e}"}
+        watchdog.cancel()
         if rank == 0:
             line["sharded"] = rec
     if rank == 0:
