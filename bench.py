@@ -75,6 +75,23 @@ def spawn_ranks(args) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PANDORA_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # wait for all of them; a rank that fails leaves the others waiting at a barrier or inside a collective: give them a moment
+    # (they may be printing the line), then end the ranks this process started rather than hang until a communicator times out
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 30.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
     codes = [p.wait() for p in procs]
     return max(abs(c) for c in codes)
 
