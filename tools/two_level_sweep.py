@@ -47,6 +47,7 @@ def timed_more():
     return "any %.3f ms, primary %.3f ms" % (timed_one(d_rays, out_any, pa.capi.ANY), timed_one(d_prim, out_prim, pa.capi.CLOSEST))
 
 
+print("checksum", {k: float(v.double().sum()) for k, v in out.items() if torch.is_tensor(v)}, flush=True)
 settings = [dict(), dict(), dict(top=2, trefill=32, trips=8)]
 for s in settings:
     ctx.set_ray_layout(s.get("lanes", 0))
