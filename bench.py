@@ -22,6 +22,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import resource
 import socket
 import subprocess
 import sys
@@ -54,7 +55,8 @@ def parse_args():
     ap.add_argument("--city-blocks", type=int, default=24, help="two-level / sharded scene: city blocks per side (24 -> 11.4 M triangles)")
     ap.add_argument("--svdag-defer", type=int, default=0, help="two-level: SVDAG casts of passes with at least this many rays run as a kernel of their own (pgpu_set_svdag_defer; 0 = inside the episode, the default)")
     ap.add_argument("--svdag", type=int, default=64, help="two-level / sharded scene: SVDAG resolution (0 = no proxy geometry, svdagRes 0 in the reference)")
-    ap.add_argument("--sharded-side", type=int, default=2048, help="N > 1: primary image side per rank of the sharded record")
+    ap.add_argument("--sharded-side", type=int, default=4096, help="N > 1: primary image side per rank of the sharded record (batch ~ side^2 diffuse rays per rank)")
+    ap.add_argument("--sharded-blocks", type=int, default=64, help="N > 1: city blocks per side of the sharded record's scene (64 -> 80.8 M triangles, 2048 batching points, ~10 GB of host memory per rank while building; 89 -> 156 M triangles, Moana's unique-triangle count, ~20 GB per rank)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded record")
     ap.add_argument("--sharded-timeout", type=int, default=420, help="seconds after which the sharded record is given up and the line printed without it")
     ap.add_argument("--force-sharded", action="store_true", help="N = 1: run the sharded record too (one rank owns every batching point; rehearsal of the N > 1 path)")
@@ -286,14 +288,20 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
 
     t0 = time.perf_counter()
     ctx = pa.accel.Context(dev.index)
-    mesh, tl = city_scene(pa, args.city_blocks, build_group=mine, svdag=args.svdag, ctx=ctx)
+    mesh, tl = city_scene(pa, args.sharded_blocks, build_group=mine, svdag=args.svdag, ctx=ctx)
     owner = owner_by_group["o"][np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
-    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
+    # (only the triangles of this rank's batching points go to its HBM)
+    part_pos, part_idx, remap = tl.sub_mesh(mesh.pos, mesh.idx, owner == rank)
+    if part_idx.shape[0] == 0:  # (a rank without batching points still needs a mesh to name)
+        part_pos, part_idx = np.zeros((3, 3), np.float32), np.array([[0, 1, 2]], np.uint32)
+    tl.upload(ctx, ctx.upload_mesh(part_pos, part_idx), resident=(owner == rank), prim_remap=remap)
+    mesh_bytes = float(part_pos.nbytes + part_idx.nbytes)
+    del part_pos, part_idx, remap
     sharded.comm_init(ctx, dev)  # RCCL communicator of the library's own; the unique id travels through torch.distributed
     ctx.comm_selftest()
     ctx.set_leaf_owners(owner)
     build_s = time.perf_counter() - t0
-    prim = city_camera(pa, args.city_blocks, args.sharded_side, 891379 + 7919 * rank)
+    prim = city_camera(pa, args.sharded_blocks, args.sharded_side, 891379 + 7919 * rank)
     first, _ = ctx.trace_sharded(torch.from_numpy(prim).to(dev))
     prim_id = tl.prim_ids_of(first["leaf"].cpu().numpy(), first["obj"].cpu().numpy())
     rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379 + 7919 * rank)
@@ -316,13 +324,13 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
     elapsed = time.perf_counter() - t0
     mx = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     sums = torch.tensor([n, cnt["leaf_visits"], cnt["records_routed"], cnt["exchange_bytes"], 1,
-                         sum(256 * b.n_nodes + 48 * b.leaf_idx.size for b in tl.bvhs if b is not None)], dtype=torch.float64, device=dev)
+                         sum(256 * b.n_nodes + 48 * b.leaf_idx.size for b in tl.bvhs if b is not None), mesh_bytes], dtype=torch.float64, device=dev)
     if multi:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     rec = None
     if rank == 0:
-        total_rays, visits, routed, xbytes, ranks, resident = (float(x) for x in sums.tolist())
+        total_rays, visits, routed, xbytes, ranks, resident, mesh_total = (float(x) for x in sums.tolist())
         el = float(mx.item())
         rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, %d^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (mesh.n_tris, tl.n_leaves, args.svdag, world),
                "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
@@ -330,7 +338,8 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
                "rays_per_gpu": n, "rounds": cnt["rounds"], "leaf_visits_per_ray": visits / total_rays, "records_routed_per_step": routed,
                "records_routed_fraction": routed / max(1.0, visits), "exchange_bytes_per_step_all_ranks": xbytes,
                "bytes_per_all_to_all_per_rank": xbytes / max(1.0, ranks * 2 * max(1, cnt["rounds"])),
-               "resident_bvh_bytes_total": resident, "scene_build_s_rank0": build_s}
+               "resident_bvh_bytes_total": resident, "resident_mesh_bytes_total": mesh_total, "scene_build_s_rank0": build_s,
+               "host_peak_rss_gb_rank0": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20}
     ctx.close()
     return rec
 

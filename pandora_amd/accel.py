@@ -340,10 +340,12 @@ class Context:
         _check(self._L.pgpu_upload_mesh(self._h, pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], C.byref(out)), self._h)
         return int(out.value)
 
-    def upload_bvh8(self, bvh: HostBvh8, mesh_id: int) -> int:
+    def upload_bvh8(self, bvh: HostBvh8, mesh_id: int, prim_remap=None) -> int:
+        """prim_remap: optional uint32 array, triangle id of the builder's mesh -> triangle id of the uploaded mesh `mesh_id`
+        (a rank that uploaded only the triangles of its own batching points, see sub_mesh)."""
         objs = np.empty((bvh.prim_ids.size, 2), np.uint32)
         objs[:, 0] = mesh_id
-        objs[:, 1] = bvh.prim_ids
+        objs[:, 1] = bvh.prim_ids if prim_remap is None else prim_remap[bvh.prim_ids]
         nodes = np.ascontiguousarray(bvh.nodes)
         out = C.c_uint32()
         _check(self._L.pgpu_upload_bvh8(self._h, nodes.ctypes.data, bvh.n_nodes, bvh.leaf_idx.ctypes.data, bvh.leaf_idx.size, bvh.root,
@@ -671,7 +673,24 @@ class TwoLevelScene:
         b += 112 * int(self.top.nodes.shape[0]) + 12 * n_verts
         return b + (4 * int(self.dags.words.size) if self.dags is not None else 0)
 
-    def upload(self, ctx: "Context", mesh_id: int, resident=None, streamed: bool = False):
+    def sub_mesh(self, pos, idx, resident):
+        """The part of the mesh the batching points marked in `resident` (bool array over leaf slots) need: (pos, idx, remap)
+        with remap[triangle id of the whole mesh] = triangle id in the part (MISS elsewhere). A rank of a sharded scene uploads
+        this instead of the whole mesh and hands `remap` to upload()."""
+        pos = np.asarray(pos, np.float32).reshape(-1, 3)
+        idx = np.asarray(idx, np.uint32).reshape(-1, 3)
+        order = np.asarray(self.top.leaf_order, np.int64)
+        mine = [self.groups[int(order[s])] for s in np.nonzero(np.asarray(resident, bool))[0]]
+        tri = np.concatenate(mine) if mine else np.zeros(0, np.uint32)
+        remap = np.full(idx.shape[0], capi.MISS, np.uint32)
+        remap[tri] = np.arange(tri.size, dtype=np.uint32)
+        part = idx[tri]
+        used = np.zeros(pos.shape[0], bool)
+        used[part.ravel()] = True
+        new_id = (np.cumsum(used, dtype=np.int64) - 1).astype(np.uint32)
+        return np.ascontiguousarray(pos[used]), np.ascontiguousarray(new_id[part]), remap
+
+    def upload(self, ctx: "Context", mesh_id: int, resident=None, streamed: bool = False, prim_remap=None):
         """Uploads BVHs, SVDAGs and the top level. Returns bvh ids in final leaf-slot order.
 
         resident: optional bool array over leaf slots -- only those batching points' bottom-level BVHs are
@@ -679,7 +698,9 @@ class TwoLevelScene:
         SVDAGs are small and always uploaded whole."""
         slot_of = np.empty(self.n_leaves, np.int64)
         slot_of[np.asarray(self.top.leaf_order, np.int64)] = np.arange(self.n_leaves)
-        put = ctx.stage_bvh8 if streamed else ctx.upload_bvh8  # streamed: leaves live in pinned host memory (config 5)
+        if prim_remap is not None and streamed:
+            raise ValueError("prim_remap is for resident uploads")
+        put = ctx.stage_bvh8 if streamed else (lambda b, m: ctx.upload_bvh8(b, m, prim_remap))  # streamed: leaves live in pinned host memory (config 5)
         ids = [put(b, mesh_id) if (b is not None and (resident is None or bool(resident[slot_of[i]]))) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
         if self.dags is not None:
             ctx.upload_svdags(self.dags)

@@ -14,7 +14,11 @@
 // 64-bit word, pauseable_bvh4.h:262-263).
 #include "pandora_hip.h"
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -521,30 +525,92 @@ int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32
 {
     if (!positions || !indices || !group_of_prim || !n_groups || max_prims == 0)
         return PGPU_ERR_INVALID;
-    for (size_t i = 0; i < 3 * n_triangles; ++i)
-        if (indices[i] >= n_vertices)
-            return PGPU_ERR_INVALID;
-    std::vector<Item> items;
-    items.reserve(n_triangles);
-    for (size_t p = 0; p < n_triangles; ++p)
-        items.push_back(triangleItem(positions, indices, uint32_t(p), uint32_t(p)));
-    std::vector<std::pair<size_t, size_t>> todo { { 0, n_triangles } };
-    uint32_t g = 0;
-    while (!todo.empty()) {
-        auto [b, e] = todo.back();
-        todo.pop_back();
-        if (e - b <= max_prims) {
-            for (size_t i = b; i < e; ++i)
-                group_of_prim[items[i].id] = g;
-            if (e > b)
-                ++g;
-            continue;
+    const unsigned nThreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto parallelFor = [&](size_t n, auto&& body) { // body(begin, end) on contiguous slices
+        const size_t slices = n < (size_t(1) << 16) ? 1 : nThreads;
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < slices; ++t)
+            pool.emplace_back([&, t] { body(n * t / slices, n * (t + 1) / slices); });
+        body(0, n / slices);
+        for (auto& th : pool)
+            th.join();
+    };
+    std::atomic<bool> bad { false };
+    parallelFor(3 * n_triangles, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i)
+            if (indices[i] >= n_vertices)
+                bad = true;
+    });
+    if (bad)
+        return PGPU_ERR_INVALID;
+    std::vector<Item> items(n_triangles);
+    parallelFor(n_triangles, [&](size_t b, size_t e) {
+        for (size_t p = b; p < e; ++p)
+            items[p] = triangleItem(positions, indices, uint32_t(p), uint32_t(p));
+    });
+    // The cut is a depth-first recursion whose sub-ranges are independent: a range is split by one thread, serially and in
+    // place, so the outcome does not depend on the schedule; the groups are numbered afterwards in depth-first order (=
+    // ascending position in the item array). Large right halves go to a shared stack for the other threads.
+    typedef std::pair<size_t, size_t> Range;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Range> shared { { 0, n_triangles } };
+    std::vector<Range> leaves;
+    size_t busy = 0;
+    const size_t grain = std::max(max_prims, n_triangles / (8 * size_t(nThreads)));
+    auto worker = [&] {
+        std::vector<Range> local, mine;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return !shared.empty() || busy == 0; });
+            if (shared.empty())
+                return;
+            local.assign(1, shared.back());
+            shared.pop_back();
+            ++busy;
+            lk.unlock();
+            while (!local.empty()) {
+                const auto [b, e] = local.back();
+                local.pop_back();
+                if (e - b <= max_prims) {
+                    if (e > b)
+                        mine.push_back({ b, e });
+                    continue;
+                }
+                const size_t m = splitPart(items, b, e, false);
+                if (e - m > grain) {
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        shared.push_back({ m, e });
+                    }
+                    cv.notify_one();
+                } else {
+                    local.push_back({ m, e });
+                }
+                local.push_back({ b, m });
+            }
+            lk.lock();
+            leaves.insert(leaves.end(), mine.begin(), mine.end());
+            mine.clear();
+            if (--busy == 0 && shared.empty())
+                cv.notify_all();
         }
-        const size_t m = splitPart(items, b, e, false);
-        todo.push_back({ m, e });
-        todo.push_back({ b, m });
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < (n_triangles > 4 * max_prims ? nThreads : 1u); ++t)
+            pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool)
+            th.join();
     }
-    *n_groups = g;
+    std::sort(leaves.begin(), leaves.end());
+    parallelFor(leaves.size(), [&](size_t lb, size_t le) {
+        for (size_t g = lb; g < le; ++g)
+            for (size_t i = leaves[g].first; i < leaves[g].second; ++i)
+                group_of_prim[items[i].id] = uint32_t(g);
+    });
+    *n_groups = uint32_t(leaves.size());
     return PGPU_OK;
 }
 

@@ -30,7 +30,12 @@ def main():
         owner_by_input = sharded.assign_leaves([b.n_nodes for b in tl.bvhs], world)
         owner = owner_by_input[np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
         ctx = pa.accel.Context(0)
-        tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
+        if mode == 2:  # (as bench.py does: only the triangles of this rank's batching points are uploaded)
+            part_pos, part_idx, remap = tl.sub_mesh(mesh.pos, mesh.idx, owner == rank)
+            assert 0 < part_idx.shape[0] < mesh.n_tris
+            tl.upload(ctx, ctx.upload_mesh(part_pos, part_idx), resident=(owner == rank), prim_remap=remap)
+        else:
+            tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
         rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
         d_rays = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)
         if mode == 2:

@@ -179,3 +179,21 @@ def test_svdag_sharing_across_groups():
     # three translated copies voxelise (nearly) identically: the merged array is much smaller than 3x
     assert dags.words.size < 1.5 * single.words.size
     assert dags.words_before >= 2.5 * single.words.size
+
+
+def test_sub_mesh_holds_exactly_the_resident_points_triangles():
+    """TwoLevelScene.sub_mesh (what a rank of a sharded scene uploads): the triangles of the chosen batching points, bit for
+    bit and in group order, vertices compacted, remap naming their new ids."""
+    mesh = pa.scenes.g_small()
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64)
+    for resident in (np.arange(tl.n_leaves) % 3 == 1, np.ones(tl.n_leaves, bool), np.zeros(tl.n_leaves, bool)):
+        pos, idx, remap = tl.sub_mesh(mesh.pos, mesh.idx, resident)
+        own = [tl.groups[int(tl.top.leaf_order[s])] for s in np.nonzero(resident)[0]]
+        own = np.concatenate(own) if own else np.zeros(0, np.uint32)
+        assert idx.shape == (own.size, 3) and remap.shape == (mesh.n_tris,)
+        assert np.array_equal(pos[idx], mesh.pos[mesh.idx[own]])
+        assert np.array_equal(remap[own], np.arange(own.size, dtype=np.uint32))
+        rest = np.ones(mesh.n_tris, bool)
+        rest[own] = False
+        assert np.all(remap[rest] == np.uint32(pa.capi.MISS))
+        assert pos.shape[0] == np.unique(mesh.idx[own]).size

@@ -135,3 +135,23 @@ def test_tiny_batches_through_the_round_loop(two_level, n, variant):
                 assert cnt[k] == want["counters"][k], f"n={n} counter {k}"
     finally:
         ctx.set_top_variant(0)
+
+
+def test_regrouped_mesh_upload_matches_whole_mesh(two_level):
+    """TwoLevelScene.sub_mesh + prim_remap (what a rank of a sharded scene uploads: only the triangles of its own batching
+    points, renumbered) with every point resident: the triangles arrive in another order under other ids, the hits are
+    the same. The partial case runs in tests/test_gpu_sharded.py (two ranks, each with half of the mesh)."""
+    ctx, mesh, tl, orc = two_level
+    rays = _ray_sets(mesh)["diffuse"]
+    want, wcnt = ctx.trace(rays)
+    part_pos, part_idx, remap = tl.sub_mesh(mesh.pos, mesh.idx, np.ones(tl.n_leaves, bool))
+    assert part_idx.shape[0] == mesh.n_tris and not np.array_equal(remap, np.arange(mesh.n_tris, dtype=np.uint32))
+    other = pa.accel.Context(0)
+    try:
+        tl.upload(other, other.upload_mesh(part_pos, part_idx), prim_remap=remap)
+        got, cnt = other.trace(rays)
+    finally:
+        other.close()
+    for k in ("t", "obj", "leaf", "u", "v", "visits"):
+        assert np.array_equal(_bits(got[k]), _bits(want[k])), k
+    assert cnt["leaf_visits"] == wcnt["leaf_visits"]
