@@ -44,10 +44,18 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["single", "two-level"], default="single", help="configs[1] (default, the headline) or configs[2]")
+    ap.add_argument("--config", choices=["single", "two-level", "landscape"], default="single",
+                    help="configs[1] (default, the headline), configs[2], or one GPU's part of configs[4] (instanced landscape, batching points streamed from pinned host memory)")
+    ap.add_argument("--landscape-instances", type=int, default=1_000_000)
+    ap.add_argument("--landscape-prototypes", type=int, default=64)
+    ap.add_argument("--landscape-terrain", type=int, default=1024, help="terrain grid side (2 n^2 triangles)")
+    ap.add_argument("--leaf-copy", type=int, default=0, help="landscape: 0 = one gather kernel per launch group reads the pinned images, 1 = one hipMemcpyAsync per image")
+    ap.add_argument("--leaf-cache-frac", type=float, default=0.25, help="landscape: HBM leaf cache as a fraction of the staged batching points' bytes (0 = everything resident, nothing staged)")
     ap.add_argument("--side", type=int, default=4096, help="primary-ray image side; batch ~ side^2 diffuse rays")
     ap.add_argument("--tris", type=int, default=262144)
     ap.add_argument("--kind", choices=["closest", "any"], default="closest")
+    ap.add_argument("--rays", choices=["diffuse", "shadow", "primary"], default="diffuse",
+                    help="single-level config: the ray set of SURVEY.md 8d -- R-diffuse (shuffled cosine bounces, the headline), R-shadow (hit point -> ceiling light, tfar = distance; use with --kind any) or R-primary (camera rays)")
     ap.add_argument("--tri", choices=["moller-trumbore", "watertight"], default="moller-trumbore",
                     help="leaf test: the branch the reference compiles (triangle_intersect.cpp:425-462) or its watertight variant (:340-423)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="rays of the batch the CPU port traces (and the GPU result is compared on); 0 = automatic: the whole batch for the single-level config (~20 s of CPU work), 2^21 rays for two-level")
@@ -137,7 +145,12 @@ def run_single(args, pa, torch, ctx, dev, rank):
     t_hit = first["t"].cpu().numpy()
     obj = first["obj"].cpu().numpy().view(np.uint32)
     prim_id = np.where(obj == MISS, MISS, hb.prim_ids[np.minimum(obj, hb.prim_ids.size - 1)])
-    rays = pa.scenes.diffuse_bounce_rays(mesh, prim, t_hit, prim_id, seed=891379 + 7919 * rank)
+    if args.rays == "shadow":
+        rays = pa.scenes.shadow_rays(mesh, prim, t_hit, prim_id, (10.0, 11.9, 6.0), (20.0, 11.9, 12.0), seed=891379 + 7919 * rank)
+    elif args.rays == "primary":
+        rays = prim
+    else:
+        rays = pa.scenes.diffuse_bounce_rays(mesh, prim, t_hit, prim_id, seed=891379 + 7919 * rank)
     del d_prim, first
     n = int(rays.shape[1])
     d_rays = torch.from_numpy(rays).to(dev)
@@ -173,19 +186,19 @@ def run_single(args, pa, torch, ctx, dev, rank):
             m = min(sample, 1 << 18)
             vpr = {k: cnt[k] / m for k in ("inner_visits", "leaf_pops", "tri_tests")}
             cpu = {"value": sample / (c1 - c0) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-                   "sample": f"first {sample} rays of the same R-diffuse batch; WiVeBVH8::intersect restated, {form}, {threads} threads",
+                   "sample": f"first {sample} rays of the same R-{args.rays} batch; WiVeBVH8::intersect restated, {form}, {threads} threads",
                    "avx2_over_scalar_in_container": avx2_ratio(), "gpu_matches_bit_exact": bool(same), "visits_per_ray": vpr,
                    "traversal_model_bytes_per_ray": 256.0 * vpr["inner_visits"] + 4.0 * vpr["tri_tests"] + 48.0 * vpr["tri_tests"]}
         # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command
         # (tools/pmc_passes.sh), which cannot run inside the timed process; the committed summary is quoted.
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.kind == "closest" and args.tri == "moller-trumbore" and os.path.exists(tpath):
+        if args.rays == "diffuse" and args.kind == "closest" and args.tri == "moller-trumbore" and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("rays_per_launch") == n:
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/pmc_traffic.json (" + tj["how"] + ")"
-        config = {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, args.kind),
+        config = {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-%s %s-hit" % (mesh.n_tris, args.rays, args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
                   "triangle_test": args.tri, "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -270,6 +283,81 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": traffic_src,
                     "kernel": "the round loop (topTraverseKernel + leafScan / binByLeaf + bvh8TracePairKernel, all rounds), device time between the loop's first and last event",
+                    "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "bytes_per_leaf_visit": 88, "scene_bytes": scene_bytes}
+        return config, roofline, cpu
+
+    return step, n, finish
+
+
+def run_landscape(args, pa, torch, ctx, dev, rank):
+    """One GPU's part of configs[4]: terrain + instanced tree prototypes (OfflineBVHLeaf::Instance leaves), cut into batching
+    points over the scene's objects; the prototypes are resident, the batching points' own BVH8s (terrain pieces + instance
+    leaves) are staged in pinned host memory and streamed through an HBM cache of --leaf-cache-frac of their size."""
+    n_inst = args.landscape_instances
+    size = float((n_inst * 64.0) ** 0.5)  # one tree per 64 square units
+    t0 = time.perf_counter()
+    terrain, protos, proto, mats = pa.scenes.g_landscape(n_prototypes=args.landscape_prototypes, n_instances=n_inst, terrain_n=args.landscape_terrain,
+                                                         size=size, detail=3)
+    tl = pa.accel.build_instanced_two_level(terrain.pos, terrain.idx, [(p.pos, p.idx) for p in protos], proto, mats, 65536, svdag_res=0)
+    build_s = time.perf_counter() - t0
+    streamed = args.leaf_cache_frac > 0
+    tl.upload(ctx, streamed=streamed)
+    image = [b.n_nodes * 256 + (b.leaf_idx.size + 1) * 48 + 64 * gi.size + 1024 for b, gi in zip(tl.bvhs, tl.group_insts)]
+    if streamed:
+        ctx.set_leaf_cache(max(2 * max(image), int(args.leaf_cache_frac * sum(image))))
+        ctx.set_leaf_copy(args.leaf_copy)
+    stream = torch.cuda.current_stream().cuda_stream
+    prim = pa.scenes.primary_rays((0.35 * size, 0.06 * size, 0.35 * size), (0.65 * size, 0.0, 0.65 * size), (0, 1, 0), 60, args.side, args.side, seed=891379 + 7919 * rank)
+    first, _ = ctx.trace(torch.from_numpy(prim).to(dev), stream=stream)
+    f_obj = first["obj"].cpu().numpy()
+    normals = tl.hit_normals(first["leaf"].cpu().numpy(), f_obj, first["inst"].cpu().numpy())
+    inst_hits = float((first["inst"].cpu().numpy().view(np.uint32) != MISS).mean())
+    rays = pa.scenes.diffuse_bounce_rays(None, prim, first["t"].cpu().numpy(), f_obj.view(np.uint32), seed=891379 + 7919 * rank, normals=normals)
+    del first
+    n = int(rays.shape[1])
+    d_rays = torch.from_numpy(rays).to(dev)
+    kind = pa.capi.CLOSEST if args.kind == "closest" else pa.capi.ANY
+    tri_mode = pa.capi.TRI_MT if args.tri == "moller-trumbore" else pa.capi.TRI_WATERTIGHT
+    out, cnt = ctx.trace(d_rays, kind=kind, tri_mode=tri_mode, stream=stream)
+    state = {"cnt": cnt}
+
+    def step():
+        _, state["cnt"] = ctx.trace(d_rays, kind=kind, tri_mode=tri_mode, out=out, stream=stream)
+
+    def finish(k_ms, world):
+        cnt = state["cnt"]
+        proto_tris = [int(i.reshape(-1, 3).shape[0]) for _, i in tl.protos]
+        unique_tris = terrain.n_tris + sum(proto_tris)
+        instanced_tris = terrain.n_tris + int(np.asarray(proto_tris, np.int64)[np.asarray(proto, np.int64)].sum())
+        scene_bytes = sum(image) + sum(256 * b.n_nodes + 4 * b.leaf_idx.size + 48 * t for b, t in zip(tl.proto_bvhs, proto_tris)) + 112 * int(tl.top.nodes.shape[0])
+        per_ray = 52 if args.kind == "closest" else 36
+        alg_bytes = per_ray * n + 88 * cnt["leaf_visits"] + scene_bytes
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        cpu = None
+        if not args.no_cpu:
+            import oracle_binding as ob
+            threads = max(1, min(16, os.cpu_count() or 1))
+            sample = min(n, args.cpu_sample or (1 << 20))
+            sub = np.ascontiguousarray(rays[:, :sample])
+            scene = ob.scene_from_instanced(tl)
+            c0 = time.perf_counter()
+            want = scene.trace(sub, any_hit=(args.kind == "any"), tri_mode=tri_mode, threads=threads)
+            c1 = time.perf_counter()
+            keys = ("hit", "visits") if args.kind == "any" else ("t", "obj", "leaf", "u", "v", "visits", "inst")
+            same = all(np.array_equal(out[k][:sample].cpu().numpy().view(np.uint32), want[k].view(np.uint32)) for k in keys)
+            cpu = {"value": sample / (c1 - c0) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": f"first {sample} rays of the same R-diffuse batch; PauseableBVH4::intersectT + WiVeBVH8::intersect with instance leaves (ray to instance space, nested traversal) restated in scalar C (oracle/pandora_oracle.c), {threads} pthreads",
+                   "gpu_matches_bit_exact": bool(same)}
+        config = {"workload": "configs[4], one GPU's part: synthetic instanced landscape (%d instances of %d tree prototypes on a %d-triangle terrain = %.3g instanced triangles from %d unique), %d batching points cut over the scene's objects, %s, R-diffuse %s-hit"
+                              % (n_inst, len(protos), terrain.n_tris, instanced_tris, unique_tris, tl.n_leaves,
+                                 ("batching points streamed from pinned host memory through an HBM cache of %.0f %% of their %d bytes" % (100 * args.leaf_cache_frac, sum(image))) if streamed else "everything resident", args.kind),
+                  "rays_per_gpu": n, "instances": n_inst, "instanced_triangles": instanced_tris, "unique_triangles": unique_tris, "batching_points": tl.n_leaves,
+                  "flattened_bytes_if_not_instanced": float(instanced_tris) * (48 + 256 / 3.0), "primary_rays_hitting_an_instance": inst_hits,
+                  "triangle_test": args.tri, "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n,
+                  "leaf_loads_per_step": cnt.get("leaf_loads"), "leaf_bytes_streamed_per_step": cnt.get("streamed_bytes"), "scene_build_s": build_s,
+                  "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "the round loop (topTraverseKernel + leafScan / binByLeaf + bvh8TraceInstKernel per group of cached batching points, all rounds), device time between the loop's first and last event",
                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "bytes_per_leaf_visit": 88, "scene_bytes": scene_bytes}
         return config, roofline, cpu
 
@@ -391,7 +479,7 @@ def main() -> int:
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     ctx = pa.accel.Context(dev.index)
-    step, n, finish = (run_single if args.config == "single" else run_two_level)(args, pa, torch, ctx, dev, rank)
+    step, n, finish = {"single": run_single, "two-level": run_two_level, "landscape": run_landscape}[args.config](args, pa, torch, ctx, dev, rank)
 
     for _ in range(args.warmup):
         step()

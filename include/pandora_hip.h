@@ -173,15 +173,20 @@ int pgpu_stage_bvh8_instanced(pgpu_ctx*, const void* nodes256, size_t n_nodes, c
 
 /* Leaves streamed from host memory (BASELINE config 5; CachedBVH::doMakeResident / doEvict, offline_bvh_cache.cpp:127-148):
  * pgpu_stage_bvh8 takes the same arguments as pgpu_upload_bvh8 but keeps the device image in pinned host memory; the
- * two-level loop copies it into an HBM cache slot (hipMemcpyAsync on a copy stream, least recently used slot evicted)
- * when rays are parked at its batching point. pgpu_set_leaf_cache sets the HBM budget of that cache in bytes
- * (0 = room for every staged BVH); it must hold at least one BVH. Staged ids share the id space of uploaded ones but
+ * two-level loop brings it into an HBM cache when rays are parked at its batching point. The cache is one arena used as a
+ * ring: images of different sizes are written one behind the other and the oldest ones make room (first in, first out); the
+ * images a round needs are visited in alternating order (up, then down), so that a round starts with what the previous one
+ * brought in last. The images of one launch group are pulled over PCIe by a single kernel that reads the pinned memory
+ * (pgpu_set_leaf_copy(ctx, 1): one hipMemcpyAsync per image instead), on a copy stream, overlapped with the traversal of
+ * the previous group. pgpu_set_leaf_cache sets the HBM budget of the cache in bytes (0 = room for every staged BVH); it must
+ * hold the largest image. Staged ids share the id space of uploaded ones but
  * are valid only as pgpu_leaf.bvh_id for pgpu_trace: pgpu_trace_bvh8, pgpu_trace_leaves and pgpu_trace_leaf_records return
  * PGPU_ERR_NO_SCENE on a context that holds staged BVHs. Staging another BVH (or pgpu_set_leaf_cache) empties the cache;
- * it is rebuilt, with slots that fit the largest staged image, by the next pgpu_trace. */
+ * it is rebuilt by the next pgpu_trace. */
 int pgpu_stage_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_leaf_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
 int pgpu_set_leaf_cache(pgpu_ctx*, size_t bytes);
+int pgpu_set_leaf_copy(pgpu_ctx*, int mode);
 
 /* Shared SVDAG array + one descriptor per DAG (SparseVoxelDAG members, sparse_voxel_dag.h:70-78). */
 int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags);

@@ -114,19 +114,38 @@ def partition_objects(bounds: np.ndarray, weights: np.ndarray | None, max_weight
     return out, int(ng.value)
 
 
+def transform_bounds_many(lo, hi, local_to_world) -> np.ndarray:
+    """Transform::transformToWorld(Bounds), graphics_core/transform.cpp:47-61, for n boxes [n, 3] under n matrices [n, 4, 4]:
+    the box around the 8 transformed corners -> [n, 6]. Every product is evaluated as ((c0 m0 + c1 m1) + c2 m2) + m3 in
+    float32, so one box and a million boxes give the same bits."""
+    lo = np.asarray(lo, np.float32).reshape(-1, 3)
+    hi = np.asarray(hi, np.float32).reshape(-1, 3)
+    m = np.asarray(local_to_world, np.float32).reshape(-1, 4, 4)
+    out_lo = np.full((m.shape[0], 3), np.inf, np.float32)
+    out_hi = np.full((m.shape[0], 3), -np.inf, np.float32)
+    for corner in range(8):
+        c = [(hi if corner >> a & 1 else lo)[:, a] for a in range(3)]
+        row = lambda r: ((c[0] * m[:, r, 0] + c[1] * m[:, r, 1]) + c[2] * m[:, r, 2]) + m[:, r, 3]
+        w = row(3)
+        p = np.stack([row(0) / w, row(1) / w, row(2) / w], axis=1)
+        out_lo = np.minimum(out_lo, p)
+        out_hi = np.maximum(out_hi, p)
+    return np.concatenate([out_lo, out_hi], axis=1)
+
+
 def transform_bounds(lo, hi, local_to_world) -> np.ndarray:
-    """Transform::transformToWorld(Bounds), graphics_core/transform.cpp:47-61: the box around the 8 transformed corners."""
-    m = np.asarray(local_to_world, np.float32).reshape(4, 4)
-    c = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float32)
-    w = c @ m.T
-    w = w[:, :3] / w[:, 3:4]
-    return np.concatenate([w.min(axis=0), w.max(axis=0)]).astype(np.float32)
+    return transform_bounds_many(np.asarray(lo)[None], np.asarray(hi)[None], np.asarray(local_to_world)[None])[0]
+
+
+def world_to_local_rows_many(local_to_world) -> np.ndarray:
+    """Rows 0..2 of Transform::m_inverseMatrix (transform.cpp:7-11) of n matrices as [n, 12] floats, row-major."""
+    m = np.asarray(local_to_world, np.float64).reshape(-1, 4, 4)
+    inv = np.linalg.inv(m) if m.shape[0] else m
+    return np.ascontiguousarray(inv[:, :3, :].astype(np.float32)).reshape(-1, 12)
 
 
 def world_to_local_rows(local_to_world) -> np.ndarray:
-    """Rows 0..2 of Transform::m_inverseMatrix (transform.cpp:7-11) as 12 floats, row-major."""
-    inv = np.linalg.inv(np.asarray(local_to_world, np.float64).reshape(4, 4))
-    return np.ascontiguousarray(inv[:3, :].astype(np.float32)).reshape(12)
+    return world_to_local_rows_many(np.asarray(local_to_world)[None])[0]
 
 
 @dataclass
@@ -368,21 +387,35 @@ class Context:
         for instance k of `instances` = list of (bvh id, world_to_local 12 floats). pgpu_upload_bvh8_instanced /
         pgpu_stage_bvh8_instanced."""
         objs = np.ascontiguousarray(objs, np.uint32).reshape(-1, 2)
-        inst = (capi.InstanceDesc * max(1, len(instances or [])))()
-        for k, (bid, m) in enumerate(instances or []):
-            inst[k].bvh_id = int(bid)
-            inst[k].world_to_local = (C.c_float * 12)(*[float(x) for x in np.asarray(m, np.float32).reshape(-1)[:12]])
+        # pgpu_instance: {uint32 bvh_id; float world_to_local[12]} = 13 words per instance
+        if isinstance(instances, tuple):  # (bvh ids uint32[n], rows float32[n, 12])
+            ids, rows = instances
+            n_inst = int(np.asarray(ids).size)
+            inst = np.empty((n_inst, 13), np.uint32)
+            inst[:, 0] = ids
+            inst[:, 1:] = np.ascontiguousarray(rows, np.float32).reshape(n_inst, 12).view(np.uint32)
+        else:
+            n_inst = len(instances or [])
+            inst = np.empty((n_inst, 13), np.uint32)
+            for k, (bid, m) in enumerate(instances or []):
+                inst[k, 0] = int(bid)
+                inst[k, 1:] = np.asarray(m, np.float32).reshape(-1)[:12].view(np.uint32)
+        assert C.sizeof(capi.InstanceDesc) == 52
         nodes = np.ascontiguousarray(bvh.nodes)
         out = C.c_uint32()
         fn = self._L.pgpu_stage_bvh8_instanced if staged else self._L.pgpu_upload_bvh8_instanced
         _check(fn(self._h, nodes.ctypes.data, bvh.n_nodes, bvh.leaf_idx.ctypes.data, bvh.leaf_idx.size, bvh.root, objs.ctypes.data, objs.shape[0],
-                  C.cast(inst, C.c_void_p) if instances else None, len(instances or []), C.byref(out)), self._h)
-        if instances:
+                  C.c_void_p(inst.ctypes.data) if n_inst else None, n_inst, C.byref(out)), self._h)
+        if n_inst:
             self.instanced = True
         return int(out.value)
 
     def set_leaf_cache(self, n_bytes: int):
         _check(self._L.pgpu_set_leaf_cache(self._h, int(n_bytes)), self._h)
+
+    def set_leaf_copy(self, mode: int):
+        """How staged images reach the HBM cache: 0 = one gather kernel per launch group (default), 1 = one hipMemcpyAsync per image."""
+        _check(self._L.pgpu_set_leaf_copy(self._h, int(mode)), self._h)
 
     def upload_svdags(self, dags: HostSvdags):
         descs = np.ascontiguousarray(dags.descs)
@@ -768,13 +801,49 @@ class InstancedTwoLevelScene:
     def n_leaves(self) -> int:
         return len(self.bvhs)
 
+    def hit_normals(self, leaf, obj, inst) -> np.ndarray:
+        """World-space geometric normal [n, 3] of every hit record (leaf slot, leaf-object index, instance leaf object or MISS)
+        of a trace through this scene; rows of misses are zero. A hit inside an instance is a triangle of the prototype: its
+        normal goes to world space with the inverse transpose of the instance's matrix."""
+        leaf, obj, inst = (np.asarray(a).view(np.uint32).astype(np.int64) for a in (leaf, obj, inst))
+        out = np.zeros((obj.size, 3), np.float64)
+        miss = int(capi.MISS)
+        order = np.asarray(self.top.leaf_order, np.int64) if self.top is not None else np.zeros(1, np.int64)
+        group = order[np.minimum(leaf, order.size - 1)]
+        n_tris = np.array([t.size for t in self.group_tris], np.int64)
+        n_inst = np.array([t.size for t in self.group_insts], np.int64)
+        tri_cat = np.concatenate(self.group_tris + [np.zeros(0, np.uint32)]).astype(np.int64)
+        inst_cat = np.concatenate(self.group_insts + [np.zeros(0, np.int64)]).astype(np.int64)
+        tri_start = np.concatenate([[0], np.cumsum(n_tris)])
+        inst_start = np.concatenate([[0], np.cumsum(n_inst)])
+
+        def tri_normals(pos, idx, prim):
+            t = idx[prim].astype(np.int64)
+            p0, p1, p2 = (pos[t[:, c]].astype(np.float64) for c in range(3))
+            return np.cross(p1 - p0, p2 - p0)
+
+        plain = np.nonzero((obj != miss) & (inst == miss))[0]
+        out[plain] = tri_normals(self.pos, self.idx, tri_cat[tri_start[group[plain]] + obj[plain]])
+        nested = np.nonzero((obj != miss) & (inst != miss))[0]
+        if nested.size:
+            k = inst_cat[inst_start[group[nested]] + (inst[nested] - n_tris[group[nested]])]
+            w2l = world_to_local_rows_many(self.inst_matrix[k]).reshape(-1, 3, 4).astype(np.float64)
+            proto = np.asarray(self.inst_proto, np.int64)[k]
+            for q in np.unique(proto):
+                sel = proto == q
+                ppos, pidx = self.protos[int(q)]
+                local = tri_normals(ppos.reshape(-1, 3), pidx.reshape(-1, 3), self.proto_bvhs[int(q)].prim_ids[obj[nested[sel]]])
+                out[nested[sel]] = np.einsum("nij,ni->nj", w2l[sel][:, :, :3], local)
+        return out
+
     def upload(self, ctx: "Context", streamed: bool = False, resident=None):
         """Prototypes are uploaded resident (they are shared by every batching point); the batching points' own BVHs are
         uploaded, or staged in host memory when `streamed`. Returns bvh ids per batching point (input order).
         resident: optional bool array over leaf slots (batching points sharded over several GPUs): only those points' BVHs
         are uploaded here, the others are NO_BVH; every rank holds all prototypes."""
         mesh_id = ctx.upload_mesh(self.pos, self.idx)
-        proto_ids = [ctx.upload_bvh8(b, ctx.upload_mesh(p, i)) for b, (p, i) in zip(self.proto_bvhs, self.protos)]
+        proto_ids = np.array([ctx.upload_bvh8(b, ctx.upload_mesh(p, i)) for b, (p, i) in zip(self.proto_bvhs, self.protos)], np.uint32)
+        w2l = world_to_local_rows_many(self.inst_matrix)
         slot_of = None
         if resident is not None:
             slot_of = np.empty(self.n_leaves, np.int64)
@@ -790,7 +859,7 @@ class InstancedTwoLevelScene:
             objs[:tris.size, 1] = tris
             objs[tris.size:, 0] = capi.INSTANCE
             objs[tris.size:, 1] = np.arange(insts.size)
-            table = [(proto_ids[int(self.inst_proto[k])], world_to_local_rows(self.inst_matrix[k])) for k in insts]
+            table = (proto_ids[self.inst_proto[insts]], w2l[insts])
             ids.append(ctx.upload_bvh8_objects(bvh, objs, table, staged=streamed))
         if self.top is not None:
             if self.dags is not None:
@@ -822,26 +891,45 @@ def build_instanced_two_level(pos, idx, protos, inst_proto, inst_matrix, prims_p
     for p, tris in enumerate(pieces):
         piece_bounds[p, :3] = tri_lo[tris].min(axis=0)
         piece_bounds[p, 3:] = tri_hi[tris].max(axis=0)
-    proto_box = [(np.asarray(p, np.float32).reshape(-1, 3).min(axis=0), np.asarray(p, np.float32).reshape(-1, 3).max(axis=0)) for p, _ in protos]
-    inst_bounds = np.stack([transform_bounds(*proto_box[int(inst_proto[k])], inst_matrix[k]) for k in range(inst_proto.size)]) if inst_proto.size else np.zeros((0, 6), np.float32)
+    proto_lo = np.stack([np.asarray(p, np.float32).reshape(-1, 3).min(axis=0) for p, _ in protos]) if protos else np.zeros((0, 3), np.float32)
+    proto_hi = np.stack([np.asarray(p, np.float32).reshape(-1, 3).max(axis=0) for p, _ in protos]) if protos else np.zeros((0, 3), np.float32)
+    inst_bounds = transform_bounds_many(proto_lo[inst_proto], proto_hi[inst_proto], inst_matrix) if inst_proto.size else np.zeros((0, 6), np.float32)
     # createSubScenes (batching.cpp:38-265): cut over the objects. An instance weighs a fraction of its prototype: it adds
     # traversal work to a batching point but no geometry (own heuristic; the reference counts the instanced scene's primitives).
     obj_bounds = np.concatenate([piece_bounds, inst_bounds])
-    weights = np.concatenate([counts.astype(np.uint64), np.array([max(1, protos[int(k)][1].shape[0] // 64) for k in inst_proto], np.uint64)])
+    proto_weight = np.array([max(1, np.asarray(i).reshape(-1, 3).shape[0] // 64) for _, i in protos], np.uint64)
+    weights = np.concatenate([counts.astype(np.uint64), proto_weight[inst_proto] if inst_proto.size else np.zeros(0, np.uint64)])
     group_of, ng = partition_objects(obj_bounds, weights, prims_per_batching_point)
-    group_tris, group_insts, bvhs = [], [], []
+    # members of every group: its pieces' triangles (pieces ascending, triangles ascending inside a piece), then its instances (ascending)
+    tri_group = group_of[:n_pieces][piece_of]
+    tri_order = np.lexsort((np.arange(nt), piece_of, tri_group)).astype(np.uint32)
+    tri_starts = np.concatenate([[0], np.cumsum(np.bincount(tri_group, minlength=ng))])
+    inst_group = group_of[n_pieces:]
+    inst_order = np.argsort(inst_group, kind="stable")
+    inst_starts = np.concatenate([[0], np.cumsum(np.bincount(inst_group, minlength=ng))])
+    group_tris, group_insts = [], []
     bounds = np.empty((ng, 6), np.float32)
-    for g in range(ng):
-        members = np.nonzero(group_of == g)[0]
-        tris = np.concatenate([pieces[m] for m in members if m < n_pieces] + [np.zeros(0, np.uint32)]).astype(np.uint32)
-        insts = np.array([m - n_pieces for m in members if m >= n_pieces], np.int64)
+
+    def build(g):
+        tris = np.ascontiguousarray(tri_order[tri_starts[g]:tri_starts[g + 1]])
+        insts = np.ascontiguousarray(inst_order[inst_starts[g]:inst_starts[g + 1]]).astype(np.int64)
         boxes = np.concatenate([np.concatenate([tri_lo[tris], tri_hi[tris]], axis=1), inst_bounds[insts]]).astype(np.float32)
         alone = np.concatenate([np.zeros(tris.size, np.uint8), np.ones(insts.size, np.uint8)])
+        return tris, insts, build_bvh8_boxes(boxes, alone), np.concatenate([boxes[:, :3].min(axis=0), boxes[:, 3:].max(axis=0)])
+
+    workers = max(1, min(16, os.cpu_count() or 1, ng))
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            built = list(pool.map(build, range(ng)))
+    else:
+        built = [build(g) for g in range(ng)]
+    bvhs = []
+    for g, (tris, insts, bvh, box) in enumerate(built):
         group_tris.append(tris)
         group_insts.append(insts)
-        bvhs.append(build_bvh8_boxes(boxes, alone))
-        bounds[g, :3] = boxes[:, :3].min(axis=0)
-        bounds[g, 3:] = boxes[:, 3:].max(axis=0)
+        bvhs.append(bvh)
+        bounds[g] = box
     top = build_top_bvh4(bounds) if ng >= 2 else None
     dags = None
     if svdag_res > 0 and top is not None:

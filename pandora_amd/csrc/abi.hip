@@ -55,22 +55,24 @@ int syncBvhTable(pgpu_ctx* c)
     return PGPU_OK;
 }
 
-// Staged BVHs lose their slots and the arena is freed: the cache is rebuilt (empty) at the next pgpu_trace.
+// Staged BVHs lose their place in the cache and the arena is freed: the cache is rebuilt (empty) at the next pgpu_trace.
 int dropLeafCache(pgpu_ctx* c)
 {
-    if (c->cacheArena || !c->slots.empty())
+    if (c->cacheArena || !c->ring.empty())
         HIP_TRY(c, hipDeviceSynchronize());
     for (size_t i = 0; i < c->bvhs.size(); ++i)
         if (i < c->staged.size() && c->staged[i].host) {
-            c->staged[i].slot = -1;
+            c->staged[i].resident = false;
+            c->staged[i].lastLaunch = -1;
             c->bvhs[i].nodes = nullptr;
             c->bvhs[i].tris = nullptr;
         }
-    c->slots.clear();
+    c->ring.clear();
+    c->ringWrite = 0;
     if (c->cacheArena)
         HIP_TRY(c, hipFree(c->cacheArena));
     c->cacheArena = nullptr;
-    c->slotBytes = 0;
+    c->cacheBytes = 0;
     c->bvhTableDirty = true;
     return PGPU_OK;
 }
@@ -287,6 +289,10 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipFree(c->cacheArena);
     if (c->copyDone)
         (void)hipEventDestroy(c->copyDone);
+    if (c->copyTableHost)
+        (void)hipHostFree(c->copyTableHost);
+    if (c->copyTableDev)
+        (void)hipFree(c->copyTableDev);
     for (hipEvent_t e : c->roundEv)
         if (e)
             (void)hipEventDestroy(e);
@@ -595,6 +601,14 @@ int pgpu_set_leaf_cache(pgpu_ctx* c, size_t bytes)
     if (rc != PGPU_OK)
         return rc;
     c->cacheBudget = bytes;
+    return PGPU_OK;
+}
+
+int pgpu_set_leaf_copy(pgpu_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 1)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_set_leaf_copy: mode is 0 (gather kernel) or 1 (one hipMemcpyAsync per image)");
+    c->leafCopyMode = mode;
     return PGPU_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels.h"
 #include "pandora_hip.h"
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -15,17 +16,16 @@ struct DeviceBuffer {
     size_t bytes = 0;
 };
 
-// A bottom-level BVH kept in pinned host memory and copied into an HBM cache slot when rays reach it
+// A bottom-level BVH kept in pinned host memory and copied into the HBM leaf cache when rays reach it
 // (BASELINE config 5; the reference's CachedBVH::doMakeResident / doEvict, offline_bvh_cache.cpp:127-148).
 struct StagedBvh {
     unsigned char* host = nullptr; // pinned: the 256-byte nodes, then (256-aligned) the 48-byte triangle records, then the instance table
     size_t nodeBytes = 0, triBytes = 0, instBytes = 0;
-    int slot = -1; // cache slot it currently occupies
-};
-struct CacheSlot {
-    int bvh = -1;
-    uint64_t lastUse = 0;
-    int lastLaunch = -1; // index into launchEvents: recorded on the compute stream after the last launch that read the slot
+    bool resident = false;
+    size_t offset = 0;      // where in the cache arena (resident only)
+    int lastLaunch = -1;    // index into launchEvents: recorded on the compute stream after the last launch that read the image
+    uint64_t pinGroup = 0;  // the launch group (a counter) that needs the image: it is not evicted while that group is being formed
+    size_t imageBytes() const { return nodeBytes + triBytes + instBytes; }
 };
 
 struct Comm;
@@ -85,9 +85,17 @@ struct pgpu_ctx {
     // streamed leaves
     std::vector<StagedBvh> staged;               // indexed by bvh id; host == nullptr for HBM-resident ones
     std::vector<pandora_hip::TopLeafDev> topLeavesHost;
-    size_t nStaged = 0, cacheBudget = 0, slotBytes = 0;
+    size_t nStaged = 0, cacheBudget = 0;
+    // The cache is a ring: images of different sizes are written one behind the other and the oldest ones make room (first in,
+    // first out). `ring` = the resident BVH ids, oldest first.
     unsigned char* cacheArena = nullptr;
-    std::vector<CacheSlot> slots;
+    size_t cacheBytes = 0, ringWrite = 0;
+    std::deque<uint32_t> ring;
+    uint64_t groupClock = 0;
+    int leafCopyMode = 0;   // pgpu_set_leaf_copy: 0 = one gather kernel per launch group reads the pinned images, 1 = one hipMemcpyAsync per image
+    void* copyTableHost = nullptr; // pinned: the gather kernel's segments and the BVH-table entries that changed, one run per launch group
+    void* copyTableDev = nullptr;
+    size_t copyTableCap = 0, copyTableNext = 0; // in 64-byte records
     hipStream_t copyStream = nullptr;
     hipEvent_t copyDone = nullptr;
     std::vector<pandora_hip::SvdagDev> dagsHost; // host copy of the descriptors (for the per-point records, LeafDagDev)
@@ -101,7 +109,6 @@ struct pgpu_ctx {
     hipEvent_t roundEv[2] = { nullptr, nullptr };
     std::vector<hipEvent_t> launchEvents; // ring: one event per bottom-level launch of the streaming path (a later record of the
     size_t launchEventNext = 0;           // same ring entry is a later point of the compute stream, so waiting on it stays safe)
-    uint64_t useClock = 0;
 };
 
 struct pgpu_host_svdags;

@@ -233,4 +233,22 @@ inline uint32_t blocksPerCU(int requested, uint32_t stackEntries, uint32_t lanes
 }
 hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream);
 
+// Streamed leaves (top_abi.hip): what one launch group brings into the HBM leaf cache. 64-byte records, written by the host into
+// pinned memory and copied to the device in one piece: first the segments of the gather kernel, then the BVH-table entries that
+// changed (images that arrived, images that were evicted).
+struct LeafCopySeg {
+    const void* src; // pinned host memory
+    void* dst;       // cache arena
+    uint64_t bytes;  // a multiple of 16
+    uint64_t chunk0; // index of the segment's first 16 KiB chunk among all chunks of the group
+    uint64_t pad[4];
+};
+struct LeafTableFix {
+    Bvh8Dev entry;
+    uint32_t id;
+};
+static_assert(sizeof(LeafCopySeg) == 64 && sizeof(LeafTableFix) <= 64, "one 64-byte record each");
+hipError_t launchLeafGather(const LeafCopySeg* segs, uint32_t nSegs, uint32_t nChunks, uint32_t blocks, hipStream_t stream);
+hipError_t launchLeafTableFix(const unsigned char* fixes64, uint32_t nFixes, Bvh8Dev* table, hipStream_t stream);
+
 } // namespace pandora_hip

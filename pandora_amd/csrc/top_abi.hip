@@ -24,25 +24,28 @@ int uploadOwned(pgpu_ctx* c, const T* host, size_t n, T** dev)
     return PGPU_OK;
 }
 
-// Builds the (empty) HBM cache for staged BVHs: equal slots, each large enough for the largest staged image.
+// Builds the (empty) HBM cache for staged BVHs: one arena of pgpu_set_leaf_cache bytes (default: everything staged fits), used
+// as a ring -- images of different sizes are written one behind the other, the oldest make room.
 int ensureLeafCache(pgpu_ctx* c)
 {
     if (c->nStaged == 0 || c->cacheArena)
         return PGPU_OK;
-    size_t slotBytes = 0;
+    size_t largest = 0, total = 0;
     for (const StagedBvh& s : c->staged)
-        if (s.host)
-            slotBytes = std::max(slotBytes, s.nodeBytes + s.triBytes + s.instBytes);
-    slotBytes = std::max<size_t>(alignUp(slotBytes), 256);
-    size_t nSlots = c->nStaged;
+        if (s.host) {
+            largest = std::max(largest, alignUp(s.imageBytes()));
+            total += alignUp(s.imageBytes());
+        }
+    size_t bytes = std::max<size_t>(total, 256);
     if (c->cacheBudget) {
-        if (c->cacheBudget < slotBytes)
+        if (c->cacheBudget < largest)
             return fail(c, PGPU_ERR_INVALID, "pgpu_trace: the leaf cache (pgpu_set_leaf_cache) is smaller than the largest staged BVH");
-        nSlots = std::min(nSlots, c->cacheBudget / slotBytes);
+        bytes = std::min(bytes, c->cacheBudget & ~size_t(255));
     }
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->cacheArena), nSlots * slotBytes));
-    c->slotBytes = slotBytes;
-    c->slots.assign(nSlots, CacheSlot {});
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->cacheArena), bytes));
+    c->cacheBytes = bytes;
+    c->ringWrite = 0;
+    c->ring.clear();
     if (c->launchEvents.empty()) {
         c->launchEvents.resize(64);
         for (hipEvent_t& e : c->launchEvents)
@@ -52,46 +55,139 @@ int ensureLeafCache(pgpu_ctx* c)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
     if (!c->copyDone)
         HIP_TRY(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
+    // room for the largest possible launch group (every staged BVH arrives and every one leaves), twice
+    const size_t cap = 4 * c->nStaged + 64;
+    if (cap > c->copyTableCap) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        if (c->copyTableHost)
+            HIP_TRY(c, hipHostFree(c->copyTableHost));
+        if (c->copyTableDev)
+            HIP_TRY(c, hipFree(c->copyTableDev));
+        c->copyTableHost = c->copyTableDev = nullptr;
+        c->copyTableCap = 0;
+        HIP_TRY(c, hipHostMalloc(&c->copyTableHost, cap * 64));
+        HIP_TRY(c, hipMalloc(&c->copyTableDev, cap * 64));
+        c->copyTableCap = cap;
+        c->copyTableNext = 0;
+    }
     return PGPU_OK;
 }
 
-// Makes staged BVH `id` resident (no-op if it is); `pinned` marks the slots the current launch group needs.
-// Copies run on the copy stream, behind the last launch that read the slot being recycled.
-int makeResident(pgpu_ctx* c, uint32_t id, std::vector<uint8_t>& pinned, bool* copied, std::vector<uint32_t>& evicted)
+// What one launch group of the streaming path brings in and throws out.
+struct LeafGroupPlan {
+    std::vector<uint32_t> arrived, evicted, touched;
+    std::vector<int> waitLaunches; // launch events the copies must wait for: the last readers of the space being overwritten
+};
+
+// Gives staged BVH `id` a place in the ring for launch group `group` (no-op if it is resident). Returns false -- and changes
+// nothing -- when that needs the space of an image the same group uses: the group is complete then.
+bool ringPlace(pgpu_ctx* c, uint32_t id, uint64_t group, LeafGroupPlan& plan)
 {
     StagedBvh& s = c->staged[id];
-    if (s.slot >= 0) {
-        pinned[size_t(s.slot)] = 1;
-        c->slots[size_t(s.slot)].lastUse = ++c->useClock;
-        return PGPU_OK;
+    if (s.resident) {
+        if (s.pinGroup != group)
+            plan.touched.push_back(id);
+        s.pinGroup = group;
+        return true;
     }
-    int victim = -1;
-    for (size_t i = 0; i < c->slots.size(); ++i)
-        if (!pinned[i] && (victim < 0 || c->slots[i].lastUse < c->slots[size_t(victim)].lastUse))
-            victim = int(i);
-    if (victim < 0)
-        return fail(c, PGPU_ERR_INVALID, "leaf cache: no free slot (internal)");
-    CacheSlot& slot = c->slots[size_t(victim)];
-    if (slot.bvh >= 0) { // evict (CachedBVH::doEvict): the device table entry is nulled too, so a work item that names it is dropped
-        c->staged[size_t(slot.bvh)].slot = -1;
-        c->bvhs[size_t(slot.bvh)].nodes = nullptr;
-        c->bvhs[size_t(slot.bvh)].tris = nullptr;
-        evicted.push_back(uint32_t(slot.bvh));
+    const size_t bytes = alignUp(s.imageBytes()), cap = c->cacheBytes;
+    if (c->ring.empty())
+        c->ringWrite = 0;
+    const size_t w = c->ringWrite;
+    const bool wrap = w + bytes > cap;
+    auto overlaps = [&](const StagedBvh& r, size_t lo, size_t hi) { return r.offset < hi && r.offset + alignUp(r.imageBytes()) > lo; };
+    // the images in the way are the oldest ones: a prefix of the ring
+    size_t victims = 0;
+    for (; victims < c->ring.size(); ++victims) {
+        const StagedBvh& r = c->staged[c->ring[victims]];
+        const bool inTheWay = wrap ? (overlaps(r, w, cap) || overlaps(r, 0, bytes)) : overlaps(r, w, w + bytes);
+        if (!inTheWay)
+            break;
+        if (r.pinGroup == group)
+            return false;
     }
-    if (slot.lastLaunch >= 0)
-        HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->launchEvents[size_t(slot.lastLaunch)], 0));
-    unsigned char* dst = c->cacheArena + size_t(victim) * c->slotBytes;
-    HIP_TRY(c, hipMemcpyAsync(dst, s.host, s.nodeBytes + s.triBytes + s.instBytes, hipMemcpyHostToDevice, c->copyStream));
+    for (size_t k = 0; k < victims; ++k) { // evict (CachedBVH::doEvict): the device table entry is nulled too, so a work item that names it is dropped
+        const uint32_t v = c->ring.front();
+        c->ring.pop_front();
+        StagedBvh& r = c->staged[v];
+        r.resident = false;
+        if (r.lastLaunch >= 0)
+            plan.waitLaunches.push_back(r.lastLaunch);
+        r.lastLaunch = -1;
+        c->bvhs[v].nodes = nullptr;
+        c->bvhs[v].tris = nullptr;
+        c->bvhs[v].inst = nullptr;
+        plan.evicted.push_back(v);
+    }
+    s.offset = wrap ? 0 : w;
+    c->ringWrite = s.offset + bytes;
+    s.resident = true;
+    s.pinGroup = group;
+    s.lastLaunch = -1;
+    unsigned char* dst = c->cacheArena + s.offset;
     c->bvhs[id].nodes = dst;
     c->bvhs[id].tris = dst + s.nodeBytes;
     c->bvhs[id].inst = s.instBytes ? dst + s.nodeBytes + s.triBytes : nullptr;
-    s.slot = victim;
-    slot.bvh = int(id);
-    slot.lastUse = ++c->useClock;
-    pinned[size_t(victim)] = 1;
+    c->ring.push_back(id);
+    plan.arrived.push_back(id);
+    plan.touched.push_back(id);
     c->counters.leaf_loads += 1;
-    c->counters.streamed_bytes += s.nodeBytes + s.triBytes + s.instBytes;
-    *copied = true;
+    c->counters.streamed_bytes += s.imageBytes();
+    return true;
+}
+
+// Queues the copies of a launch group on the copy stream and the changes of the device BVH table on the compute stream (behind
+// the copies, and behind the previous launch, which may still read the entries of the images that leave).
+int commitLeafGroup(pgpu_ctx* c, const LeafGroupPlan& plan, hipStream_t stream)
+{
+    if (plan.arrived.empty() && plan.evicted.empty())
+        return PGPU_OK;
+    for (int ev : plan.waitLaunches)
+        HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->launchEvents[size_t(ev)], 0));
+    const size_t nSeg = c->leafCopyMode == 0 ? plan.arrived.size() : 0, nFix = plan.arrived.size() + plan.evicted.size();
+    if (c->copyTableNext + nSeg + nFix > c->copyTableCap) { // (the table is reused from its start: everything that read it must be done)
+        HIP_TRY(c, hipStreamSynchronize(c->copyStream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        c->copyTableNext = 0;
+    }
+    unsigned char* const host = static_cast<unsigned char*>(c->copyTableHost) + c->copyTableNext * 64;
+    unsigned char* const dev = static_cast<unsigned char*>(c->copyTableDev) + c->copyTableNext * 64;
+    c->copyTableNext += nSeg + nFix;
+    uint64_t chunks = 0;
+    for (size_t i = 0; i < plan.arrived.size(); ++i) {
+        const uint32_t id = plan.arrived[i];
+        const StagedBvh& s = c->staged[id];
+        if (c->leafCopyMode == 0) {
+            LeafCopySeg seg {};
+            seg.src = s.host;
+            seg.dst = c->cacheArena + s.offset;
+            seg.bytes = (s.imageBytes() + 15) & ~size_t(15); // (the pinned image and its place in the arena are 256-byte multiples)
+            seg.chunk0 = chunks;
+            chunks += (seg.bytes + 16383) / 16384;
+            std::memcpy(host + i * 64, &seg, 64);
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(c->cacheArena + s.offset, s.host, s.imageBytes(), hipMemcpyHostToDevice, c->copyStream));
+        }
+    }
+    size_t f = 0;
+    auto putFix = [&](uint32_t id) {
+        LeafTableFix fix {};
+        fix.entry = c->bvhs[id];
+        fix.id = id;
+        std::memcpy(host + (nSeg + f++) * 64, &fix, sizeof(fix));
+    };
+    for (uint32_t id : plan.evicted)
+        if (!c->staged[id].resident) // (an image evicted and brought back within one group keeps its new entry)
+            putFix(id);
+    for (uint32_t id : plan.arrived)
+        if (c->staged[id].resident)
+            putFix(id);
+    HIP_TRY(c, hipMemcpyAsync(dev, host, (nSeg + f) * 64, hipMemcpyHostToDevice, c->copyStream));
+    if (nSeg)
+        HIP_TRY(c, launchLeafGather(reinterpret_cast<const LeafCopySeg*>(dev), uint32_t(nSeg), uint32_t(chunks), uint32_t(c->numCUs) * 4u, c->copyStream));
+    HIP_TRY(c, hipEventRecord(c->copyDone, c->copyStream));
+    HIP_TRY(c, hipStreamWaitEvent(stream, c->copyDone, 0));
+    HIP_TRY(c, launchLeafTableFix(dev + nSeg * 64, uint32_t(f), c->bvhTable, stream));
     return PGPU_OK;
 }
 
@@ -503,8 +599,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     rc = ensureLeafCache(c);
     if (rc != PGPU_OK)
         return rc;
-    std::vector<uint32_t> hLeafCount, hLeafStart;
-    std::vector<uint8_t> pinned;
+    std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder;
     uint64_t leafLoads0 = c->counters.leaf_loads = 0, streamed0 = c->counters.streamed_bytes = 0;
     (void)leafLoads0;
     (void)streamed0;
@@ -673,54 +768,39 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         } else {
             // Leaves streamed from host memory: the work list is sorted by batching point, so consecutive points whose
             // BVHs fit the cache together form one launch; the copies of the next group run on the copy stream while
-            // this group traces (a slot is recycled only behind the last launch that read it).
+            // this group traces (an image is overwritten only behind the last launch that read it). Odd rounds walk the
+            // points downwards: what the previous round brought in last is used first.
             hLeafCount.resize(nl);
             hLeafStart.resize(nl);
             HIP_TRY(c, hipMemcpyAsync(hLeafCount.data(), dLeafCount, nl * 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipMemcpyAsync(hLeafStart.data(), dLeafStart, nl * 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipStreamSynchronize(stream));
             const uint32_t* workRayAll = workRayOut;
-            size_t l = 0;
-            while (l < nl) {
-                if (hLeafCount[l] == 0) {
-                    ++l;
-                    continue;
-                }
-                pinned.assign(c->slots.size(), 0);
-                size_t pinnedCount = 0;
-                bool copied = false;
-                const size_t first = l;
-                size_t last = l;
-                std::vector<uint32_t> touched, movedIds;
-                for (; l < nl; ++l) {
-                    if (hLeafCount[l] == 0)
-                        continue;
+            visitOrder.clear();
+            for (size_t l = 0; l < nl; ++l)
+                if (hLeafCount[l] != 0)
+                    visitOrder.push_back(uint32_t(l));
+            if (rounds % 2 == 0) // (`rounds` was incremented above: the first round walks upwards)
+                std::reverse(visitOrder.begin(), visitOrder.end());
+            size_t at = 0;
+            while (at < visitOrder.size()) {
+                const uint64_t group = ++c->groupClock;
+                LeafGroupPlan plan;
+                uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                size_t members = 0;
+                for (; at < visitOrder.size(); ++at, ++members) {
+                    const uint32_t l = visitOrder[at];
                     const uint32_t id = c->topLeavesHost[l].bvh;
-                    if (id < c->staged.size() && c->staged[id].host) {
-                        const int slot = c->staged[id].slot;
-                        if (slot < 0 || !pinned[size_t(slot)]) {
-                            if (pinnedCount == c->slots.size())
-                                break; // the cache is full of BVHs this launch needs: launch, then go on
-                            ++pinnedCount;
-                            bool moved = false;
-                            rc = makeResident(c, id, pinned, &moved, movedIds);
-                            if (rc != PGPU_OK)
-                                return rc;
-                            copied = copied || moved;
-                            touched.push_back(id);
-                            if (moved)
-                                movedIds.push_back(id);
-                        }
-                    }
-                    last = l;
+                    if (id < c->staged.size() && c->staged[id].host && !ringPlace(c, id, group, plan))
+                        break; // the cache is full of BVHs this launch needs: launch, then go on
+                    lo = std::min(lo, hLeafStart[l]);
+                    hi = std::max(hi, hLeafStart[l] + hLeafCount[l]);
                 }
-                const uint32_t lo = hLeafStart[first], hi = hLeafStart[last] + hLeafCount[last];
-                if (copied) {
-                    HIP_TRY(c, hipEventRecord(c->copyDone, c->copyStream));
-                    HIP_TRY(c, hipStreamWaitEvent(stream, c->copyDone, 0));
-                }
-                for (uint32_t id : movedIds) // device copy of the table entries that moved
-                    HIP_TRY(c, hipMemcpyAsync(c->bvhTable + id, &c->bvhs[id], sizeof(Bvh8Dev), hipMemcpyHostToDevice, stream));
+                if (members == 0)
+                    return fail(c, PGPU_ERR_INVALID, "leaf cache: no room for a single BVH (internal)");
+                rc = commitLeafGroup(c, plan, stream);
+                if (rc != PGPU_OK)
+                    return rc;
                 HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
                 ba.work_ray = workRayAll + lo;
                 ba.work_bvh = dWorkBvh + lo;
@@ -731,11 +811,12 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 if (rc != PGPU_OK)
                     return rc;
                 HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
-                if (!touched.empty()) {
+                if (!plan.touched.empty()) {
                     const size_t ev = c->launchEventNext++ % c->launchEvents.size();
                     HIP_TRY(c, hipEventRecord(c->launchEvents[ev], stream));
-                    for (uint32_t id : touched)
-                        c->slots[size_t(c->staged[id].slot)].lastLaunch = int(ev);
+                    for (uint32_t id : plan.touched)
+                        if (c->staged[id].resident)
+                            c->staged[id].lastLaunch = int(ev);
                 }
             }
             ba.work_bvh = dWorkBvh;

@@ -350,14 +350,16 @@ def geometric_normals(mesh: Mesh, prim: np.ndarray) -> np.ndarray:
     return _normalize(np.cross(p1 - p0, p2 - p0).astype(np.float64)).astype(np.float32)
 
 
-def diffuse_bounce_rays(mesh: Mesh, rays: np.ndarray, t_hit: np.ndarray, prim: np.ndarray, seed: int = 891379,
-                        shuffle_seed: int | None = 94892380) -> np.ndarray:
-    """One cosine-weighted bounce ray per ray that hit something; order shuffled (incoherent set)."""
+def diffuse_bounce_rays(mesh: Mesh | None, rays: np.ndarray, t_hit: np.ndarray, prim: np.ndarray, seed: int = 891379,
+                        shuffle_seed: int | None = 94892380, normals: np.ndarray | None = None) -> np.ndarray:
+    """One cosine-weighted bounce ray per ray that hit something; order shuffled (incoherent set).
+    normals: optional [n, 3] geometric normals of the hits (scenes whose hits are not triangles of one mesh: instances);
+    `prim` then only says which rays hit (anything but 0xFFFFFFFF)."""
     hit = prim != np.uint32(0xFFFFFFFF)
     o = rays[0:3, hit].T.astype(np.float32)
     d = rays[3:6, hit].T.astype(np.float32)
     p = o + t_hit[hit, None].astype(np.float32) * d
-    ng = geometric_normals(mesh, prim[hit])
+    ng = geometric_normals(mesh, prim[hit]) if normals is None else _normalize(np.asarray(normals, np.float64)[hit]).astype(np.float32)
     flip = np.einsum("ij,ij->i", ng, -d) < 0  # triangle_intersect.cpp:459-460
     ng[flip] = -ng[flip]
     n = p.shape[0]

@@ -127,7 +127,20 @@ class OracleBvh8:
         self.pos = np.ascontiguousarray(pos, np.float32)
         self.idx = np.ascontiguousarray(idx, np.uint32)
         self.inst = None
-        if instances is not None:
+        if isinstance(instances, tuple):
+            # (children: list of OracleBvh8, child index per leaf object int[n] (-1 = primitive), rows float32[n, 12]): the same
+            # table filled through numpy, for scenes with 10^5+ instances
+            children, which, rows = instances
+            self.children = list(children)
+            which = np.asarray(which, np.int64)
+            table = np.zeros(which.size, np.dtype([("child", np.uint64), ("w2l", np.float32, (12,))], align=True))
+            assert table.itemsize == C.sizeof(Instance)
+            addr = np.array([C.addressof(c.c) for c in self.children] + [0], np.uint64)
+            table["child"] = addr[np.where(which >= 0, which, len(self.children))]
+            table["w2l"] = np.asarray(rows, np.float32).reshape(-1, 12)
+            self.inst_np = table
+            self.inst = (Instance * which.size).from_buffer(table)
+        elif instances is not None:
             self.children = [i[0] for i in instances if i is not None]  # keep them alive
             self.inst = (Instance * len(instances))()
             for j, i in enumerate(instances):
@@ -299,11 +312,13 @@ def bvhs_from_instanced(tl):
     import pandora_amd as pa
     protos = [OracleBvh8(b.nodes, b.leaf_idx, b.root, b.prim_ids, p, i) for b, (p, i) in zip(tl.proto_bvhs, tl.protos)]
     out = []
+    w2l = pa.accel.world_to_local_rows_many(tl.inst_matrix)
     for g, bvh in enumerate(tl.bvhs):
         tris, insts = tl.group_tris[g], tl.group_insts[g]
         prim_of_obj = np.concatenate([tris, np.zeros(insts.size, np.uint32)]).astype(np.uint32)
-        table = [None] * tris.size + [(protos[int(tl.inst_proto[k])], pa.accel.world_to_local_rows(tl.inst_matrix[k])) for k in insts]
-        out.append(OracleBvh8(bvh.nodes, bvh.leaf_idx, bvh.root, prim_of_obj, tl.pos, tl.idx, instances=table))
+        which = np.concatenate([np.full(tris.size, -1, np.int64), np.asarray(tl.inst_proto, np.int64)[insts]])
+        rows = np.concatenate([np.zeros((tris.size, 12), np.float32), w2l[insts]])
+        out.append(OracleBvh8(bvh.nodes, bvh.leaf_idx, bvh.root, prim_of_obj, tl.pos, tl.idx, instances=(protos, which, rows)))
     return out
 
 
