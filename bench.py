@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--landscape-instances", type=int, default=1_000_000)
     ap.add_argument("--landscape-prototypes", type=int, default=64)
     ap.add_argument("--landscape-terrain", type=int, default=1024, help="terrain grid side (2 n^2 triangles)")
+    ap.add_argument("--leaf-hold", type=int, default=-1, help="landscape: pgpu_set_leaf_hold (image bytes per waiting ray before a point is loaded; 0 = never wait, -1 = the library's default)")
     ap.add_argument("--leaf-copy", type=int, default=0, help="landscape: 0 = one gather kernel per launch group reads the pinned images, 1 = one hipMemcpyAsync per image")
     ap.add_argument("--leaf-cache-frac", type=float, default=0.25, help="landscape: HBM leaf cache as a fraction of the staged batching points' bytes (0 = everything resident, nothing staged)")
     ap.add_argument("--side", type=int, default=4096, help="primary-ray image side; batch ~ side^2 diffuse rays")
@@ -306,6 +307,8 @@ def run_landscape(args, pa, torch, ctx, dev, rank):
     if streamed:
         ctx.set_leaf_cache(max(2 * max(image), int(args.leaf_cache_frac * sum(image))))
         ctx.set_leaf_copy(args.leaf_copy)
+        if args.leaf_hold >= 0:
+            ctx.set_leaf_hold(args.leaf_hold)
     stream = torch.cuda.current_stream().cuda_stream
     prim = pa.scenes.primary_rays((0.35 * size, 0.06 * size, 0.35 * size), (0.65 * size, 0.0, 0.65 * size), (0, 1, 0), 60, args.side, args.side, seed=891379 + 7919 * rank)
     first, _ = ctx.trace(torch.from_numpy(prim).to(dev), stream=stream)

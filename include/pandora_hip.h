@@ -178,7 +178,12 @@ int pgpu_stage_bvh8_instanced(pgpu_ctx*, const void* nodes256, size_t n_nodes, c
  * images a round needs are visited in alternating order (up, then down), so that a round starts with what the previous one
  * brought in last. The images of one launch group are pulled over PCIe by a single kernel that reads the pinned memory
  * (pgpu_set_leaf_copy(ctx, 1): one hipMemcpyAsync per image instead), on a copy stream, overlapped with the traversal of
- * the previous group. pgpu_set_leaf_cache sets the HBM budget of the cache in bytes (0 = room for every staged BVH); it must
+ * the previous group. Rays wait: like the reference, which drains its fullest queue first and lets the others fill
+ * (task_graph.cpp:19-56), a round loads an image that is not in the cache only once its batching point holds one ray per
+ * `image_bytes_per_ray` bytes of image (pgpu_set_leaf_hold; default 256, 0 = every point with a ray is loaded every round);
+ * the rays of the other points stay parked and join the next round's queues (when no point qualifies, the points with the
+ * most rays per byte are taken, one cache-full of them). Results do not depend on any of this; pgpu_counters.rounds does.
+ * pgpu_set_leaf_cache sets the HBM budget of the cache in bytes (0 = room for every staged BVH); it must
  * hold the largest image. Staged ids share the id space of uploaded ones but
  * are valid only as pgpu_leaf.bvh_id for pgpu_trace: pgpu_trace_bvh8, pgpu_trace_leaves and pgpu_trace_leaf_records return
  * PGPU_ERR_NO_SCENE on a context that holds staged BVHs. Staging another BVH (or pgpu_set_leaf_cache) empties the cache;
@@ -187,6 +192,7 @@ int pgpu_stage_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint3
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
 int pgpu_set_leaf_cache(pgpu_ctx*, size_t bytes);
 int pgpu_set_leaf_copy(pgpu_ctx*, int mode);
+int pgpu_set_leaf_hold(pgpu_ctx*, uint32_t image_bytes_per_ray);
 
 /* Shared SVDAG array + one descriptor per DAG (SparseVoxelDAG members, sparse_voxel_dag.h:70-78). */
 int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags);

@@ -413,6 +413,11 @@ class Context:
     def set_leaf_cache(self, n_bytes: int):
         _check(self._L.pgpu_set_leaf_cache(self._h, int(n_bytes)), self._h)
 
+    def set_leaf_hold(self, image_bytes_per_ray: int):
+        """Streamed leaves: an image that is not in the cache is loaded once its batching point holds one ray per this many
+        bytes of image; until then the point's rays stay parked (0 = never wait). Default 256."""
+        _check(self._L.pgpu_set_leaf_hold(self._h, int(image_bytes_per_ray)), self._h)
+
     def set_leaf_copy(self, mode: int):
         """How staged images reach the HBM cache: 0 = one gather kernel per launch group (default), 1 = one hipMemcpyAsync per image."""
         _check(self._L.pgpu_set_leaf_copy(self._h, int(mode)), self._h)

@@ -604,6 +604,14 @@ int pgpu_set_leaf_cache(pgpu_ctx* c, size_t bytes)
     return PGPU_OK;
 }
 
+int pgpu_set_leaf_hold(pgpu_ctx* c, uint32_t image_bytes_per_ray)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    c->leafHoldBytesPerRay = image_bytes_per_ray;
+    return PGPU_OK;
+}
+
 int pgpu_set_leaf_copy(pgpu_ctx* c, int mode)
 {
     if (!c || mode < 0 || mode > 1)

@@ -92,6 +92,7 @@ struct pgpu_ctx {
     size_t cacheBytes = 0, ringWrite = 0;
     std::deque<uint32_t> ring;
     uint64_t groupClock = 0;
+    uint32_t leafHoldBytesPerRay = 256; // pgpu_set_leaf_hold: an image that is not in the cache is loaded once its point holds a ray per this many bytes (0: always)
     int leafCopyMode = 0;   // pgpu_set_leaf_copy: 0 = one gather kernel per launch group reads the pinned images, 1 = one hipMemcpyAsync per image
     void* copyTableHost = nullptr; // pinned: the gather kernel's segments and the BVH-table entries that changed, one run per launch group
     void* copyTableDev = nullptr;

@@ -58,7 +58,52 @@ __global__ void leafTableFixKernel(const unsigned char* __restrict__ fixes64, ui
     }
 }
 
+// Rays that stay parked for another round (their batching point's image is not worth loading yet, see top_abi.hip): the
+// counts of the held rays join the round's per-point counts before the scan ...
+__global__ void addCountsKernel(uint32_t* __restrict__ count, const uint32_t* __restrict__ add, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        count[i] += add[i];
+}
+
+// ... and after the round the binned list (sorted by batching point) is split: the rays of the points that were traced form
+// the next round's list, the rays of the others the next held list. dst[l] = where point l's rays go; bit 31 = held.
+__global__ __launch_bounds__(256) void splitByLeafKernel(const uint32_t* __restrict__ workRay, const uint32_t* __restrict__ leafStart,
+    const uint32_t* __restrict__ leafCount, const uint32_t* __restrict__ dst, uint32_t nLeaves, uint32_t* __restrict__ nextActive,
+    uint32_t* __restrict__ heldRay, uint32_t* __restrict__ heldLeaf)
+{
+    for (uint32_t l = blockIdx.x; l < nLeaves; l += gridDim.x) {
+        const uint32_t n = leafCount[l], from = leafStart[l], d = dst[l];
+        const bool held = (d & 0x80000000u) != 0u;
+        const uint32_t to = d & 0x7FFFFFFFu;
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint32_t ray = workRay[from + i];
+            if (held) {
+                heldRay[to + i] = ray;
+                heldLeaf[to + i] = l;
+            } else {
+                nextActive[to + i] = ray;
+            }
+        }
+    }
+}
+
 } // namespace
+
+hipError_t launchAddCounts(uint32_t* count, const uint32_t* add, uint32_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(addCountsKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, count, add, n);
+    return hipGetLastError();
+}
+
+hipError_t launchSplitByLeaf(const uint32_t* workRay, const uint32_t* leafStart, const uint32_t* leafCount, const uint32_t* dst, uint32_t nLeaves,
+    uint32_t* nextActive, uint32_t* heldRay, uint32_t* heldLeaf, uint32_t blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(splitByLeafKernel, dim3(blocks < nLeaves ? blocks : nLeaves), dim3(256), 0, stream, workRay, leafStart, leafCount, dst, nLeaves,
+        nextActive, heldRay, heldLeaf);
+    return hipGetLastError();
+}
 
 hipError_t launchLeafGather(const LeafCopySeg* segs, uint32_t nSegs, uint32_t nChunks, uint32_t blocks, hipStream_t stream)
 {

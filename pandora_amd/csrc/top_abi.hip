@@ -477,6 +477,15 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         oRays = carve(n * 8 * 4);
         oHits = carve(n * 8 * 4);
     }
+    // streamed leaves: rays held at batching points whose image is not loaded yet (ray, point; double buffered), the list of the
+    // rays that go on, and two per-point arrays the host fills every round
+    size_t oHeld = 0, oNextActive = 0, oHeldCount = 0, oSplitDst = 0;
+    if (c->nStaged > 0) {
+        oHeld = carve(n * 4 * 4);
+        oNextActive = carve(n * 4);
+        oHeldCount = carve(nl * 4);
+        oSplitDst = carve(nl * 4);
+    }
     int rc = ensure(c, c->work, off);
     if (rc != PGPU_OK)
         return rc;
@@ -599,7 +608,20 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     rc = ensureLeafCache(c);
     if (rc != PGPU_OK)
         return rc;
-    std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder;
+    std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder, hHeldCount, hSplitDst;
+    std::vector<uint8_t> traced;
+    uint32_t* dHeldRay[2] = { nullptr, nullptr };
+    uint32_t* dHeldLeaf[2] = { nullptr, nullptr };
+    uint32_t *dNextActive = nullptr, *dHeldCount = nullptr, *dSplitDst = nullptr;
+    if (streaming) {
+        uint32_t* h = reinterpret_cast<uint32_t*>(wb + oHeld);
+        dHeldRay[0] = h, dHeldLeaf[0] = h + n, dHeldRay[1] = h + 2 * n, dHeldLeaf[1] = h + 3 * n;
+        dNextActive = reinterpret_cast<uint32_t*>(wb + oNextActive);
+        dHeldCount = reinterpret_cast<uint32_t*>(wb + oHeldCount);
+        dSplitDst = reinterpret_cast<uint32_t*>(wb + oSplitDst);
+    }
+    uint32_t nHeld = 0, heldBuf = 0;   // rays waiting at batching points that were not traced in the round they arrived
+    uint64_t guardRounds = 0;          // rounds since rays were last held (the pause budget of a ray counts from there)
     uint64_t leafLoads0 = c->counters.leaf_loads = 0, streamed0 = c->counters.streamed_bytes = 0;
     (void)leafLoads0;
     (void)streamed0;
@@ -705,12 +727,14 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         nActive = 0; // (skips the loop below)
     }
     bool firstEpisode = true;
-    while (nActive > 0) {
+    while (nActive > 0 || nHeld > 0) {
         HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
         ta.active = active;
         ta.n_active = nActive;
         ta.n_active_dev = nullptr;
-        ta.may_park = rounds < nl ? 1u : 0u; // a ray pauses at most once per batching point
+        ta.may_park = guardRounds < nl ? 1u : 0u; // a ray pauses at most once per batching point
+        ++guardRounds;
+        if (nActive > 0) {
         // the rays as 32-byte records (see the loop above): written by the first episode, read by the later ones and by the
         // pair-layout bottom level (streamed scenes; the deferred-cast passes of the first round read the caller's arrays)
         ta.ray_aos = (pairLists && !firstEpisode) ? dRayAos : nullptr;
@@ -743,20 +767,30 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ta.only_culled = 1u;
         }
         HIP_TRY(c, launchTopTraverse(ta, kind, topBlocks, stream));
+        } // nActive > 0
+        if (nHeld > 0) // the rays still waiting from earlier rounds are part of this round's queues
+            HIP_TRY(c, launchAddCounts(dLeafCount, dHeldCount, uint32_t(nl), stream));
         // The scan and the binning do not depend on the host knowing the count: queue them behind the traversal,
         // then fetch the number of parked rays (it sizes the bottom-level launch and ends the loop).
         HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), dParkedCount, stream));
         uint32_t* const workRayOut = (active == dWorkRay) ? dWorkRayAlt : dWorkRay; // binning reads the current list
-        HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, nActive, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
-                       std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nActive + 255u) / 256u)), stream));
+        if (nActive > 0)
+            HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, nActive, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
+                           std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nActive + 255u) / 256u)), stream));
+        if (nHeld > 0)
+            HIP_TRY(c, launchBinByLeaf(dHeldRay[heldBuf], dHeldLeaf[heldBuf], nHeld, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh,
+                           dWorkLeaf, std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nHeld + 255u) / 256u)), stream));
         uint32_t parked = 0;
         HIP_TRY(c, hipMemcpyAsync(&parked, dParkedCount, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(c, hipStreamSynchronize(stream));
         if (parked == 0)
             break;
         ++rounds;
-        leafVisits += parked;
+        if (!streaming)
+            leafVisits += parked;
         ba.work_ray = workRayOut;
+        uint32_t nextActiveCount = parked, nextHeld = 0;
+        const uint32_t* nextActive = workRayOut;
         if (!streaming) {
             HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
             ba.n_work = parked;
@@ -776,10 +810,75 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             HIP_TRY(c, hipMemcpyAsync(hLeafStart.data(), dLeafStart, nl * 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipStreamSynchronize(stream));
             const uint32_t* workRayAll = workRayOut;
+            // Which queues are flushed this round. The reference drains the fullest queue first and lets the others fill
+            // (task_graph.cpp:19-56): an image that is not in the cache is loaded once its point holds one ray per
+            // leafHoldBytesPerRay bytes of image; the rays of the other points stay parked. When nothing qualifies, the points
+            // with the most rays per byte are taken, one cache-full of them. After 4 n_leaves + 64 rounds nothing is held any more.
+            traced.assign(nl, 0);
+            const bool mayHold = c->leafHoldBytesPerRay != 0u && rounds < 4 * uint64_t(nl) + 64;
+            auto stagedImage = [&](size_t l) -> const StagedBvh* {
+                const uint32_t id = c->topLeavesHost[l].bvh;
+                return (id < c->staged.size() && c->staged[id].host) ? &c->staged[id] : nullptr;
+            };
+            size_t nTraced = 0, nWaiting = 0;
+            for (size_t l = 0; l < nl; ++l) {
+                if (hLeafCount[l] == 0)
+                    continue;
+                const StagedBvh* im = stagedImage(l);
+                if (!mayHold || !im || im->resident || uint64_t(hLeafCount[l]) * c->leafHoldBytesPerRay >= im->imageBytes()) {
+                    traced[l] = 1;
+                    ++nTraced;
+                } else {
+                    ++nWaiting;
+                }
+            }
+            if (nTraced == 0) {
+                visitOrder.clear();
+                for (size_t l = 0; l < nl; ++l)
+                    if (hLeafCount[l] != 0)
+                        visitOrder.push_back(uint32_t(l));
+                std::sort(visitOrder.begin(), visitOrder.end(), [&](uint32_t x, uint32_t y) {
+                    const double rx = double(hLeafCount[x]) / double(stagedImage(x)->imageBytes()), ry = double(hLeafCount[y]) / double(stagedImage(y)->imageBytes());
+                    return rx > ry || (rx == ry && x < y);
+                });
+                size_t bytes = 0;
+                for (uint32_t l : visitOrder) {
+                    const size_t b = alignUp(stagedImage(l)->imageBytes());
+                    if (nTraced && bytes + b > c->cacheBytes)
+                        break;
+                    bytes += b;
+                    traced[l] = 1;
+                    ++nTraced;
+                    --nWaiting;
+                }
+            }
             visitOrder.clear();
+            uint64_t tracedRays = 0;
             for (size_t l = 0; l < nl; ++l)
-                if (hLeafCount[l] != 0)
+                if (traced[l]) {
                     visitOrder.push_back(uint32_t(l));
+                    tracedRays += hLeafCount[l];
+                }
+            leafVisits += tracedRays;
+            if (nWaiting) { // split the binned list: the traced points' rays go on, the others wait (one small kernel; skipped when nothing waits)
+                hHeldCount.assign(nl, 0);
+                hSplitDst.assign(nl, 0);
+                uint32_t a0 = 0, h0 = 0;
+                for (size_t l = 0; l < nl; ++l) {
+                    if (traced[l] || hLeafCount[l] == 0) {
+                        hSplitDst[l] = a0;
+                        a0 += hLeafCount[l];
+                    } else {
+                        hSplitDst[l] = h0 | 0x80000000u;
+                        hHeldCount[l] = hLeafCount[l];
+                        h0 += hLeafCount[l];
+                    }
+                }
+                nextActiveCount = a0;
+                nextHeld = h0;
+                nextActive = dNextActive;
+                guardRounds = 0;
+            }
             if (rounds % 2 == 0) // (`rounds` was incremented above: the first round walks upwards)
                 std::reverse(visitOrder.begin(), visitOrder.end());
             size_t at = 0;
@@ -821,9 +920,18 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             }
             ba.work_bvh = dWorkBvh;
             ba.work_tag = dWorkLeaf;
+            if (nextHeld) {
+                // (pageable sources: the copies are staged before the calls return)
+                HIP_TRY(c, hipMemcpyAsync(dSplitDst, hSplitDst.data(), nl * 4, hipMemcpyHostToDevice, stream));
+                HIP_TRY(c, hipMemcpyAsync(dHeldCount, hHeldCount.data(), nl * 4, hipMemcpyHostToDevice, stream));
+                HIP_TRY(c, launchSplitByLeaf(workRayOut, dLeafStart, dLeafCount, dSplitDst, uint32_t(nl), dNextActive, dHeldRay[heldBuf ^ 1u],
+                               dHeldLeaf[heldBuf ^ 1u], uint32_t(c->numCUs) * 4u, stream));
+                heldBuf ^= 1u;
+            }
         }
-        active = workRayOut;
-        nActive = parked;
+        active = nextActive;
+        nActive = nextActiveCount;
+        nHeld = nextHeld;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
 
