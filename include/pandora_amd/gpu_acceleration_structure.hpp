@@ -79,6 +79,10 @@ struct AdapterOptions {
     unsigned hostThreads = 0;        // worker threads of flush(); 0 = min(16, hardware threads)
     size_t batchRays = size_t(1) << 20; // rays per GPU call
     int triangleTest = PGPU_TRI_MT;
+    // The reference builder's botLevelBVHCacheSize (offline_batching_acceleration_structure.h:108-109), in bytes: 0 = every
+    // batching point's BVH is resident in HBM; otherwise the BVHs stay in pinned host memory and are streamed through an HBM
+    // cache of this size (pgpu_stage_bvh8 / pgpu_set_leaf_cache; it must hold the largest one). Not with LeafSharded.
+    size_t botLevelBVHCacheBytes = 0;
 };
 
 inline void check(int rc, pgpu_ctx* ctx, const char* what)
@@ -747,8 +751,8 @@ private:
 };
 
 // Counterpart of OfflineBatchingAccelerationStructureBuilder (offline_batching...h:106-126): same knobs
-// (primitivesPerBatchingPoint, svdagRes; 0 disables the SVDAG early-out as in :323). The geometry cache,
-// task graph and BVH cache size of the reference have no role here: everything is resident in HBM.
+// (primitivesPerBatchingPoint, svdagRes; 0 disables the SVDAG early-out as in :323; AdapterOptions::botLevelBVHCacheBytes = its
+// botLevelBVHCacheSize). The geometry cache and the task graph of the reference have no role here.
 class GpuAccelerationStructureBuilder {
 public:
     GpuAccelerationStructureBuilder(const std::vector<TriangleShape>* shapes, unsigned primitivesPerBatchingPoint, unsigned svdagRes,
@@ -874,6 +878,7 @@ public:
                 load[r] += groups[g].size();
             }
         }
+        const bool streamed = m.twoLevel && m_options.botLevelBVHCacheBytes > 0; // (a single batching point is traced single-level: resident)
         std::vector<std::vector<uint32_t>> bvhIds(nDev, std::vector<uint32_t>(nGroups, PGPU_NO_BVH));
         for (size_t d = 0; d < nDev; ++d)
             for (uint32_t g = 0; g < nGroups; ++g) {
@@ -882,9 +887,16 @@ public:
                 size_t nNodes = 0, nIdx = 0;
                 const void* nodes = pgpu_host_bvh8_nodes(built[g], &nNodes);
                 const uint32_t* li = pgpu_host_bvh8_leaf_indices(built[g], &nIdx);
-                check(pgpu_upload_bvh8(m.devices[d].ctx, nodes, nNodes, li, nIdx, pgpu_host_bvh8_root(built[g]), objs[g].data(), objs[g].size(), &bvhIds[d][g]),
-                    m.devices[d].ctx, "pgpu_upload_bvh8");
+                if (streamed)
+                    check(pgpu_stage_bvh8(m.devices[d].ctx, nodes, nNodes, li, nIdx, pgpu_host_bvh8_root(built[g]), objs[g].data(), objs[g].size(), &bvhIds[d][g]),
+                        m.devices[d].ctx, "pgpu_stage_bvh8");
+                else
+                    check(pgpu_upload_bvh8(m.devices[d].ctx, nodes, nNodes, li, nIdx, pgpu_host_bvh8_root(built[g]), objs[g].data(), objs[g].size(), &bvhIds[d][g]),
+                        m.devices[d].ctx, "pgpu_upload_bvh8");
             }
+        if (streamed)
+            for (size_t d = 0; d < nDev; ++d)
+                check(pgpu_set_leaf_cache(m.devices[d].ctx, m_options.botLevelBVHCacheBytes), m.devices[d].ctx, "pgpu_set_leaf_cache");
         if (!m.twoLevel) {
             // the reference refuses a single batching point (pauseable_bvh4.h:180); serve it single-level
             for (size_t d = 0; d < nDev; ++d)
@@ -959,6 +971,8 @@ private:
             throw std::runtime_error("GpuAccelerationStructureBuilder: no shapes");
         if (m_options.devices.empty())
             throw std::runtime_error("GpuAccelerationStructureBuilder: no devices");
+        if (m_options.botLevelBVHCacheBytes > 0 && m_options.multiGpu == MultiGpu::LeafSharded)
+            throw std::runtime_error("GpuAccelerationStructureBuilder: botLevelBVHCacheBytes (streamed leaves) cannot be combined with MultiGpu::LeafSharded");
     }
 
     // pgpu_comm_init is collective: one thread per context joins

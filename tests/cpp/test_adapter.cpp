@@ -213,6 +213,12 @@ static int multi()
     AdapterOptions rccl = one; // one rank, but through pgpu_comm_init (RCCL) + pgpu_trace_sharded
     rccl.multiGpu = MultiGpu::LeafSharded;
     const Outcome r = runScene(shapes, rccl, n, 4);
+    AdapterOptions streamed = one; // batching points in pinned host memory, streamed through a small HBM cache (botLevelBVHCacheSize)
+    streamed.botLevelBVHCacheBytes = size_t(1) << 20;
+    const Outcome st = runScene(shapes, streamed, n, 4);
+    AdapterOptions streamedTwo = two;
+    streamedTwo.botLevelBVHCacheBytes = size_t(3) << 19;
+    const Outcome st2 = runScene(shapes, streamedTwo, n, 4);
     size_t hits = 0, shadowed = 0;
     for (int i = 0; i < n; ++i) {
         hits += a.shape[size_t(i)] != 0xFFFFFFFFu;
@@ -230,6 +236,18 @@ static int multi()
     const bool okB = same(b, "two contexts, scene replicated");
     const bool okC = same(c, "two contexts, batching points sharded");
     const bool okR = same(r, "one context, sharded loop over an RCCL communicator of one rank");
+    const bool okS = same(st, "one context, batching points streamed through a 1 MiB cache");
+    const bool okS2 = same(st2, "two contexts, each streaming through a 1.5 MiB cache");
+    bool refused = false;
+    try {
+        AdapterOptions bad = sharded;
+        bad.botLevelBVHCacheBytes = size_t(1) << 20;
+        GpuAccelerationStructureBuilder b2(&shapes, 1024, 16, bad);
+    } catch (const std::exception&) {
+        refused = true;
+    }
+    if (!okS || !okS2 || !refused)
+        return 1;
     if (hits < size_t(n) / 2 || shadowed == 0 || shadowed == hits || !okB || !okC || !okR || c.counters.records_routed == 0)
         return 1;
     std::printf("adapter multi ok\n");
