@@ -310,8 +310,10 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
     const lds_u8 *rdNearX = pairEven, *rdNearY = pairEven, *rdNearZ = pairEven;
     uint32_t chunkNext = 0, chunkEnd = 0; // wave-uniform
     uint32_t range = blockIdx.x & 7u;     // blocks are dealt round-robin over the 8 XCDs
-    // (a launch sized before the list's length was known: blocks the list cannot feed leave without probing the cursors)
-    bool exhausted = false;
+    // (a launch sized before the list's length was known: blocks the list cannot feed leave without probing the cursors. Only the
+    // instanced variant reads the list's length from device memory: in the plain kernel, which is bound by instruction issue, the
+    // extra scalar state cost 3 % on the single-level benchmark)
+    bool exhausted = INST && a.n_work_dev != nullptr && blockIdx.x >= max(8u, (min(*a.n_work_dev, a.n_work) + 2u * kRaysPerWave * 4u - 1u) / (2u * kRaysPerWave * 4u));
     uint32_t statInner = 0, statLeaf = 0, statTri = 0, statIter = 0, statLeafPass = 0, statRefill = 0;
 
     // Ray set-up for the BVH `bd`: lane q of the quad brings component q of the origin (va) and of the direction (vb); lane 3
@@ -357,7 +359,11 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
                 if (lane == 0)
                     c = atomicAdd(a.cursor + range * 8u, a.chunk);
                 c = uint32_t(__builtin_amdgcn_readfirstlane(int(c)));
-                const uint32_t nWork = a.n_work, rangeSize = a.range_size;
+                uint32_t nWork = a.n_work, rangeSize = a.range_size;
+                if (INST && a.n_work_dev) {
+                    nWork = min(*a.n_work_dev, a.n_work);
+                    rangeSize = (((nWork + 7u) / 8u + a.chunk - 1u) / a.chunk) * a.chunk;
+                }
                 const uint32_t lo = range * rangeSize, hi = min(lo + rangeSize, nWork);
                 if (lo < hi && c < hi - lo) {
                     chunkNext = lo + c;
@@ -383,7 +389,14 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
                 // lane q of the quad loads component q of the origin and of the direction (lane 3: tnear, tfar)
                 const float* const loadA = q == 0 ? a.ox : (q == 1 ? a.oy : (q == 2 ? a.oz : a.tnear));
                 const float* const loadB = q == 0 ? a.dx : (q == 1 ? a.dy : (q == 2 ? a.dz : a.tfar_in));
-                setRay(loadA[rayId], loadB[rayId], bd);
+                if (INST && a.ray_aos) {
+                    // rays as 32-byte records {ox, oy, oz, tnear}{dx, dy, dz, .} (written by the first top-level episode): the quad
+                    // reads one sector instead of eight; the current far end still comes from the per-ray state
+                    const float* const rec = reinterpret_cast<const float*>(a.ray_aos + 2u * size_t(rayId));
+                    setRay(rec[q], q == 3u ? a.tfar_in[rayId] : rec[4u + q], bd);
+                } else {
+                    setRay(loadA[rayId], loadB[rayId], bd);
+                }
                 if (INST) {
                     spBase = 0;
                     curInst = hitInst = PGPU_MISS_ID;
@@ -647,8 +660,13 @@ __device__ __forceinline__ void bvh8TraceBody(const Bvh8TraceArgs a) // (by valu
             const float* const loadA = q == 0 ? a.ox : (q == 1 ? a.oy : (q == 2 ? a.oz : a.tnear));
             const float* const loadB = q == 0 ? a.dx : (q == 1 ? a.dy : (q == 2 ? a.dz : a.tfar_in));
             const float keepFar = tfar;
-            const float vb = loadB[rayId];
-            setRay(loadA[rayId], q == 3u ? keepFar : vb, a.bvhs[outerBvh]);
+            if (a.ray_aos) {
+                const float* const rec = reinterpret_cast<const float*>(a.ray_aos + 2u * size_t(rayId));
+                setRay(rec[q], q == 3u ? keepFar : rec[4u + min(q, 2u)], a.bvhs[outerBvh]);
+            } else {
+                const float vb = loadB[rayId];
+                setRay(loadA[rayId], q == 3u ? keepFar : vb, a.bvhs[outerBvh]);
+            }
             spBase = 0;
             curInst = PGPU_MISS_ID;
         } else if (st == 1 && sp == 0) {
@@ -1213,8 +1231,8 @@ size_t bvh8TraceLdsBytes(uint32_t stackEntries, uint32_t lanesPerRay)
 hipError_t launchBvh8Trace(const Bvh8TraceArgs& args, int kind, int triMode, bool stats, uint32_t blocks, hipStream_t stream)
 {
     const dim3 grid(blocks), block(256);
-    if ((args.n_work_dev || args.ray_aos) && (args.lanes_per_ray != 2u || args.instanced))
-        return hipErrorInvalidValue; // (only the pair-layout kernel reads its list length from device memory / rays as records)
+    if ((args.n_work_dev || args.ray_aos) && (args.instanced ? args.lanes_per_ray == 2u : args.lanes_per_ray != 2u))
+        return hipErrorInvalidValue; // (only the pair-layout kernel and the instanced quad kernel read their list length from device memory / rays as records)
     const size_t ldsBytes = bvh8TraceLdsBytes(args.stack_entries, args.lanes_per_ray);
 #define PANDORA_LAUNCH(ANYV, TRIV, STATV)                                                                            \
     do {                                                                                                             \

@@ -401,7 +401,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     const size_t oLeafCount = carve(nl * 4), oLeafStart = carve(nl * 4), oLeafFill = carve(nl * 4), oTotal = carve(256);
     const size_t oCounts = carve(512), oFill = carve(256), oMatrix = carve(size_t(world) * (world + 1u) * 4);
     // the rays as 32-byte records by ray id, as in pgpu_trace (Bvh8TraceArgs::ray_aos): pair-layout lists only
-    const bool rayRecords = !c->hasInstances && (c->lanesPerRay == 0u || c->lanesPerRay == 2u);
+    const bool rayRecords = c->hasInstances || c->lanesPerRay == 0u || c->lanesPerRay == 2u; // (pair kernel, or the quad kernel's instanced variant)
     const size_t oRayAos = carve(rayRecords ? nb * 32 : 0);
     rc = ensure(c, c->shardWork, off);
     if (rc != PGPU_OK)

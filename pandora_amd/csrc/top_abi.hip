@@ -654,10 +654,10 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     // work list from device memory -- the previous round's parked count -- and their launch size from the newest count the host
     // has seen (counts never grow), so the host reads a round's count a whole round late, after the next round is queued: the GPU
     // never waits for that read. The round queued behind the first empty one runs empty (a few launches of nothing).
-    // (Only the pair-layout kernel takes its list length from device memory: in the quad kernel, which is bound by instruction
-    // issue, the extra scalar state cost 3 % on the single-level benchmark. Instanced scenes and a forced quad layout therefore
-    // run round by round.)
-    const bool pairLists = !c->hasInstances && (c->lanesPerRay == 0u || c->lanesPerRay == 2u);
+    // (The pair-layout kernel and the instanced variant of the quad kernel take their list length from device memory: in the plain
+    // quad kernel, which is bound by instruction issue, the extra scalar state cost 3 % on the single-level benchmark. A forced
+    // quad layout therefore runs round by round.)
+    const bool pairLists = c->hasInstances || c->lanesPerRay == 0u || c->lanesPerRay == 2u; // (instanced scenes: the quad kernel's instanced variant does the same)
     if (!streaming && c->deferMin == 0u && c->roundLookahead && pairLists) {
         if (c->roundCountsCap < nl + 8) {
             if (c->roundCounts)
