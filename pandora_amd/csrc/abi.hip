@@ -289,6 +289,8 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipFree(c->cacheArena);
     if (c->copyDone)
         (void)hipEventDestroy(c->copyDone);
+    if (c->leafHostBuf)
+        (void)hipHostFree(c->leafHostBuf);
     if (c->copyTableHost)
         (void)hipHostFree(c->copyTableHost);
     if (c->copyTableDev)

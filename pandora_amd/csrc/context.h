@@ -97,6 +97,8 @@ struct pgpu_ctx {
     void* copyTableHost = nullptr; // pinned: the gather kernel's segments and the BVH-table entries that changed, one run per launch group
     void* copyTableDev = nullptr;
     size_t copyTableCap = 0, copyTableNext = 0; // in 64-byte records
+    uint32_t* leafHostBuf = nullptr; // pinned: per-point counts read back every round, and the two per-point arrays the host sends (3 n_leaves + 64 words)
+    size_t leafHostCap = 0;
     hipStream_t copyStream = nullptr;
     hipEvent_t copyDone = nullptr;
     std::vector<pandora_hip::SvdagDev> dagsHost; // host copy of the descriptors (for the per-point records, LeafDagDev)

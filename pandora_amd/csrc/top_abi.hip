@@ -55,6 +55,16 @@ int ensureLeafCache(pgpu_ctx* c)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
     if (!c->copyDone)
         HIP_TRY(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
+    const size_t words = 3 * size_t(c->top.n_leaves) + 64;
+    if (words > c->leafHostCap) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        if (c->leafHostBuf)
+            HIP_TRY(c, hipHostFree(c->leafHostBuf));
+        c->leafHostBuf = nullptr;
+        c->leafHostCap = 0;
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->leafHostBuf), words * 4));
+        c->leafHostCap = words;
+    }
     // room for the largest possible launch group (every staged BVH arrives and every one leaves), twice
     const size_t cap = 4 * c->nStaged + 64;
     if (cap > c->copyTableCap) {
@@ -483,8 +493,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     if (c->nStaged > 0) {
         oHeld = carve(n * 4 * 4);
         oNextActive = carve(n * 4);
-        oHeldCount = carve(nl * 4);
-        oSplitDst = carve(nl * 4);
+        oHeldCount = carve(2 * nl * 4); // held counts, then the split destinations (sent together)
+        oSplitDst = oHeldCount + nl * 4;
     }
     int rc = ensure(c, c->work, off);
     if (rc != PGPU_OK)
@@ -608,7 +618,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     rc = ensureLeafCache(c);
     if (rc != PGPU_OK)
         return rc;
-    std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder, hHeldCount, hSplitDst;
+    std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder;
     std::vector<uint8_t> traced;
     uint32_t* dHeldRay[2] = { nullptr, nullptr };
     uint32_t* dHeldLeaf[2] = { nullptr, nullptr };
@@ -781,8 +791,21 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             HIP_TRY(c, launchBinByLeaf(dHeldRay[heldBuf], dHeldLeaf[heldBuf], nHeld, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh,
                            dWorkLeaf, std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nHeld + 255u) / 256u)), stream));
         uint32_t parked = 0;
-        HIP_TRY(c, hipMemcpyAsync(&parked, dParkedCount, 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(c, hipStreamSynchronize(stream));
+        if (streaming) {
+            // one read per round: the per-point counts (pinned); the total and the starts follow from them
+            uint32_t* const pc = c->leafHostBuf;
+            HIP_TRY(c, hipMemcpyAsync(pc, dLeafCount, nl * 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipStreamSynchronize(stream));
+            hLeafCount.assign(pc, pc + nl);
+            hLeafStart.resize(nl);
+            for (size_t l = 0; l < nl; ++l) {
+                hLeafStart[l] = parked;
+                parked += hLeafCount[l];
+            }
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(&parked, dParkedCount, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipStreamSynchronize(stream));
+        }
         if (parked == 0)
             break;
         ++rounds;
@@ -804,11 +827,6 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             // BVHs fit the cache together form one launch; the copies of the next group run on the copy stream while
             // this group traces (an image is overwritten only behind the last launch that read it). Odd rounds walk the
             // points downwards: what the previous round brought in last is used first.
-            hLeafCount.resize(nl);
-            hLeafStart.resize(nl);
-            HIP_TRY(c, hipMemcpyAsync(hLeafCount.data(), dLeafCount, nl * 4, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipMemcpyAsync(hLeafStart.data(), dLeafStart, nl * 4, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipStreamSynchronize(stream));
             const uint32_t* workRayAll = workRayOut;
             // Which queues are flushed this round. The reference drains the fullest queue first and lets the others fill
             // (task_graph.cpp:19-56): an image that is not in the cache is loaded once its point holds one ray per
@@ -861,8 +879,9 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 }
             leafVisits += tracedRays;
             if (nWaiting) { // split the binned list: the traced points' rays go on, the others wait (one small kernel; skipped when nothing waits)
-                hHeldCount.assign(nl, 0);
-                hSplitDst.assign(nl, 0);
+                uint32_t* const hHeldCount = c->leafHostBuf + nl; // (pinned; read by the copies queued at the end of the round)
+                uint32_t* const hSplitDst = c->leafHostBuf + 2 * nl;
+                std::fill(hHeldCount, hHeldCount + nl, 0u);
                 uint32_t a0 = 0, h0 = 0;
                 for (size_t l = 0; l < nl; ++l) {
                     if (traced[l] || hLeafCount[l] == 0) {
@@ -921,9 +940,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ba.work_bvh = dWorkBvh;
             ba.work_tag = dWorkLeaf;
             if (nextHeld) {
-                // (pageable sources: the copies are staged before the calls return)
-                HIP_TRY(c, hipMemcpyAsync(dSplitDst, hSplitDst.data(), nl * 4, hipMemcpyHostToDevice, stream));
-                HIP_TRY(c, hipMemcpyAsync(dHeldCount, hHeldCount.data(), nl * 4, hipMemcpyHostToDevice, stream));
+                // (pinned sources, rewritten only after the next round's synchronisation)
+                HIP_TRY(c, hipMemcpyAsync(dHeldCount, c->leafHostBuf + nl, 2 * nl * 4, hipMemcpyHostToDevice, stream));
                 HIP_TRY(c, launchSplitByLeaf(workRayOut, dLeafStart, dLeafCount, dSplitDst, uint32_t(nl), dNextActive, dHeldRay[heldBuf ^ 1u],
                                dHeldLeaf[heldBuf ^ 1u], uint32_t(c->numCUs) * 4u, stream));
                 heldBuf ^= 1u;
