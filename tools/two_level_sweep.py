@@ -20,6 +20,29 @@ prim = bench.city_camera(pa, blocks, side, 891379)
 first, _ = ctx.trace(torch.from_numpy(prim).to(dev))
 prim_id = tl.prim_ids_of(first["leaf"].cpu().numpy(), first["obj"].cpu().numpy())
 rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379)
+grid = int(os.environ.get("SORT_GRID", "0"))  # upper bound for ray reordering: the batch sorted on the host by origin cell (+ direction octant), sort not timed
+if grid:
+    import numpy as np
+    lo, hi = rays[0:3].min(axis=1, keepdims=True), rays[0:3].max(axis=1, keepdims=True)
+    cell = np.minimum(grid - 1, ((rays[0:3] - lo) / (hi - lo) * grid).astype(np.int64))
+    key = (cell[0] * grid + cell[2]) * grid + cell[1]
+    if os.environ.get("SORT_OCT", "1") == "1":
+        key = key * 8 + ((rays[3] > 0) * 1 + (rays[4] > 0) * 2 + (rays[5] > 0) * 4)
+    cell_bits = int(os.environ.get("SORT_BITS", "0"))
+    if cell_bits:  # `cell_bits` bits of cell, handed out to the axes by extent (halve the longest cell side), + 3 bits of octant
+        ext = (hi - lo).ravel().astype(np.float64)
+        bits = [0, 0, 0]
+        for _ in range(cell_bits):
+            a = int(np.argmax(ext / (2.0 ** np.array(bits))))
+            bits[a] += 1
+        key = np.zeros(rays.shape[1], np.int64)
+        for a in range(3):
+            n = 1 << bits[a]
+            c = np.minimum(n - 1, ((rays[a] - lo[a]) / (hi[a] - lo[a]) * n).astype(np.int64))
+            key = key * n + c
+        key = key * 8 + ((rays[3] > 0) * 1 + (rays[4] > 0) * 2 + (rays[5] > 0) * 4)
+        print("cell bits per axis", bits, flush=True)
+    rays = np.ascontiguousarray(rays[:, np.argsort(key, kind="stable")])
 d_rays = torch.from_numpy(rays).to(dev)
 out, _ = ctx.trace(d_rays)
 
@@ -48,7 +71,7 @@ def timed_more():
 
 
 print("checksum", {k: float(v.double().sum()) for k, v in out.items() if torch.is_tensor(v)}, flush=True)
-settings = [dict(), dict(), dict(top=2, trefill=32, trips=8)]
+settings = [dict(), dict()]
 for s in settings:
     ctx.set_ray_layout(s.get("lanes", 0))
     ctx.set_round_lookahead(bool(s.get("look", 1)))
