@@ -197,3 +197,14 @@ def test_sub_mesh_holds_exactly_the_resident_points_triangles():
         rest[own] = False
         assert np.all(remap[rest] == np.uint32(pa.capi.MISS))
         assert pos.shape[0] == np.unique(mesh.idx[own]).size
+
+
+def test_partition_is_the_same_on_every_run():
+    """The triangle-level cut runs on all host threads; every rank of a sharded job computes it for itself and they must agree:
+    the groups may not depend on how the sub-ranges were scheduled."""
+    mesh = pa.scenes.g_city(3, 60000)  # ~0.5 M triangles: large enough for the worker threads to take sub-ranges
+    first, ng = pa.accel.partition_prims(mesh.pos, mesh.idx, 4096)
+    assert ng > 64 and np.bincount(first).max() <= 4096
+    for _ in range(4):
+        again, ng2 = pa.accel.partition_prims(mesh.pos, mesh.idx, 4096)
+        assert ng2 == ng and np.array_equal(again, first)
