@@ -15,7 +15,8 @@ from pandora_amd import sharded  # noqa: E402
 
 
 def main():
-    # mode 0 / 1: Python loop (torch / device records), 2: pgpu_trace_sharded, 3: pgpu_trace_sharded on the instanced landscape
+    # mode 0 / 1: Python loop (torch / device records), 2: pgpu_trace_sharded, 3: pgpu_trace_sharded on the instanced landscape,
+    # 4: pgpu_trace_sharded on a city whose BVHs every rank builds for its own batching points only
     out_dir, kind, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     device_records = bool(mode)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -25,9 +26,13 @@ def main():
         if mode == 3:
             instanced_landscape(out_dir, kind, rank, world, dev)
             return
-        mesh = pa.scenes.g_small()
-        tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=32)
-        owner_by_input = sharded.assign_leaves([b.n_nodes for b in tl.bvhs], world)
+        if mode == 4:  # a city of ~0.35 M triangles in ~60 batching points, every rank building only its own (as bench.py does)
+            mode = 2
+            mesh, tl, owner_by_input = city_scene(world, rank)
+        else:
+            mesh = pa.scenes.g_small()
+            tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=32)
+            owner_by_input = sharded.assign_leaves([b.n_nodes for b in tl.bvhs], world)
         owner = owner_by_input[np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
         ctx = pa.accel.Context(0)
         if mode == 2:  # (as bench.py does: only the triangles of this rank's batching points are uploaded)
@@ -47,7 +52,7 @@ def main():
             info = {"routed": cnt["records_routed"], "rounds": cnt["rounds"], "leaf_visits": cnt["leaf_visits"]}
             film = torch.full((5, 3), rank + 1, dtype=torch.int64, device=dev)
             ctx.film_allreduce(film)
-            assert bool((film == 3).all()), "pgpu_film_allreduce over the host-staged transport"
+            assert bool((film == world * (world + 1) // 2).all()), "pgpu_film_allreduce over the host-staged transport"
         else:
             eng = sharded.GpuEngine(ctx, dev, device_records=device_records)
             st, info = sharded.trace_sharded(eng, d_rays, owner, kind)
@@ -58,6 +63,23 @@ def main():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def city_mesh():
+    return pa.scenes.g_city(4, 20000)
+
+
+def city_scene(world, rank):
+    """(mesh, two-level scene with the BVHs of `rank`'s batching points only -- all of them when rank is None --, owner per input group)"""
+    mesh = city_mesh()
+    box = {}
+
+    def mine(sizes):
+        box["owner"] = sharded.assign_leaves(sizes, world)
+        return np.ones(len(sizes), bool) if rank is None else box["owner"] == rank
+
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 8192, svdag_res=32, build_group=mine)
+    return mesh, tl, box["owner"]
 
 
 def landscape_scene():

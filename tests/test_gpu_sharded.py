@@ -140,6 +140,48 @@ def test_two_processes_sharded_leaves(scene, kind, device_records):
     assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
 
 
+def test_four_processes_sharded_city():
+    """Four ranks (sharing the one GPU, records through host memory) on a city of ~60 batching points, each rank building and
+    uploading only its own points' BVHs and triangles, 150 K shuffled diffuse rays: several rounds with thousands of records
+    per peer and direction, buffers that grow -- results equal one context's pgpu_trace bit for bit."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import sharded_gpu_worker as worker
+    mesh, tl, _ = worker.city_scene(4, None)
+    assert tl.n_leaves >= 32
+    ctx = pa.accel.Context(0)
+    try:
+        tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+        prim = pa.scenes.primary_rays((8.0, 14.0, 8.0), (48.0, 0.0, 48.0), (0, 1, 0), 60, 400, 400)
+        first, _ = ctx.trace(prim)
+        rays = pa.scenes.diffuse_bounce_rays(mesh, prim, np.asarray(first["t"]), tl.prim_ids_of(np.asarray(first["leaf"]), np.asarray(first["obj"])))
+        got, wcnt = ctx.trace(rays)  # (numpy in, numpy out)
+        want = {k: np.asarray(v) for k, v in got.items()}
+    finally:
+        ctx.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "rays.npy"), rays)
+        procs = []
+        for r in range(4):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(pa.capi.CLOSEST), "4"], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+        parts = [dict(np.load(os.path.join(d, f"r{r}.npz"))) for r in range(4)]
+    assert sum(int(p["routed"]) for p in parts) > rays.shape[1] // 2
+    for r, p in enumerate(parts):
+        for k in ("t", "obj", "leaf", "u", "v", "visits"):
+            assert np.array_equal(_bits(p[k]), _bits(want[k])[r::4]), f"rank {r}: {k}"
+    assert sum(int(p["leaf_visits"]) for p in parts) == wcnt["leaf_visits"]
+    assert sum(int(p["svdag_tests"]) for p in parts) == wcnt["svdag_tests"]
+    assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
+
+
 @pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
 def test_two_processes_sharded_instanced_landscape(kind):
     """Instanced leaves + batching points sharded over two ranks (pgpu_trace_sharded): the instancing BVHs live on their owners,
