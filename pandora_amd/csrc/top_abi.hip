@@ -28,7 +28,21 @@ int uploadOwned(pgpu_ctx* c, const T* host, size_t n, T** dev)
 // as a ring -- images of different sizes are written one behind the other, the oldest make room.
 int ensureLeafCache(pgpu_ctx* c)
 {
-    if (c->nStaged == 0 || c->cacheArena)
+    if (c->nStaged == 0)
+        return PGPU_OK;
+    // (per-point arrays the host exchanges with the device every round: sized by the top level, which may have been replaced
+    // since the cache was built)
+    const size_t words = 3 * size_t(c->top.n_leaves) + 64;
+    if (words > c->leafHostCap) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        if (c->leafHostBuf)
+            HIP_TRY(c, hipHostFree(c->leafHostBuf));
+        c->leafHostBuf = nullptr;
+        c->leafHostCap = 0;
+        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->leafHostBuf), words * 4));
+        c->leafHostCap = words;
+    }
+    if (c->cacheArena)
         return PGPU_OK;
     size_t largest = 0, total = 0;
     for (const StagedBvh& s : c->staged)
@@ -55,16 +69,6 @@ int ensureLeafCache(pgpu_ctx* c)
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
     if (!c->copyDone)
         HIP_TRY(c, hipEventCreateWithFlags(&c->copyDone, hipEventDisableTiming));
-    const size_t words = 3 * size_t(c->top.n_leaves) + 64;
-    if (words > c->leafHostCap) {
-        HIP_TRY(c, hipDeviceSynchronize());
-        if (c->leafHostBuf)
-            HIP_TRY(c, hipHostFree(c->leafHostBuf));
-        c->leafHostBuf = nullptr;
-        c->leafHostCap = 0;
-        HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->leafHostBuf), words * 4));
-        c->leafHostCap = words;
-    }
     // room for the largest possible launch group (every staged BVH arrives and every one leaves), twice
     const size_t cap = 4 * c->nStaged + 64;
     if (cap > c->copyTableCap) {

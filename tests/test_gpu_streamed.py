@@ -133,3 +133,49 @@ def test_sharded_building_blocks_refuse_staged_contexts():
         ctx.trace_leaf_records(pa.capi.CLOSEST, pa.capi.TRI_MT, torch.zeros(9 * 4, device=dev), 4, torch.zeros(16, device=dev))
     assert e.value.code == pa.capi.ERR_NO_SCENE
     ctx.close()
+
+
+def test_streamed_city_random_cache_settings():
+    """A city of ~50 batching points with images of different sizes, 120 K shuffled diffuse rays: whatever the cache size, the
+    waiting threshold and the copy mode, the streamed trace returns the resident trace's arrays bit for bit (which
+    tests/test_gpu_scale.py holds against the oracle), and the counters that do not depend on scheduling agree."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    mesh = pa.scenes.g_city(3, 20000)
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 4096, svdag_res=16)
+    assert tl.n_leaves >= 32
+    res = pa.accel.Context(0)
+    try:
+        tl.upload(res, res.upload_mesh(mesh.pos, mesh.idx))
+        prim = pa.scenes.primary_rays((6.0, 14.0, 6.0), (36.0, 0.0, 36.0), (0, 1, 0), 60, 360, 360)
+        first, _ = res.trace(prim)
+        rays = pa.scenes.diffuse_bounce_rays(mesh, prim, np.asarray(first["t"]), tl.prim_ids_of(np.asarray(first["leaf"]), np.asarray(first["obj"])))
+        want = {kind: res.trace(rays, kind=kind) for kind in (pa.capi.CLOSEST, pa.capi.ANY)}
+    finally:
+        res.close()
+    images = [((b.n_nodes * 256 + 255) // 256) * 256 + (((b.leaf_idx.size + 1) * 48 + 255) // 256) * 256 for b in tl.bvhs]
+    assert max(images) > 2 * min(images)
+    rng = np.random.default_rng(5)
+    ctx = pa.accel.Context(0)
+    try:
+        tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=True)
+        loads = []
+        for trial in range(8):
+            budget = int(rng.uniform(max(images), sum(images)))
+            hold = int(rng.choice([0, 16, 256, 2048, 1 << 20]))
+            ctx.set_leaf_cache(budget)
+            ctx.set_leaf_hold(hold)
+            ctx.set_leaf_copy(trial & 1)
+            for kind in (pa.capi.CLOSEST, pa.capi.ANY):
+                got, cnt = ctx.trace(rays, kind=kind)
+                exp, ecnt = want[kind]
+                for k in (("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")):
+                    assert np.array_equal(_bits(got[k]), _bits(exp[k])), f"budget {budget} hold {hold}: {k}"
+                for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                    assert cnt[k] == ecnt[k], f"budget {budget} hold {hold}: {k}"
+                assert cnt["rounds"] >= ecnt["rounds"]
+                loads.append(cnt["leaf_loads"])
+        assert max(loads) > tl.n_leaves  # some setting had to bring images in more than once
+    finally:
+        ctx.close()
