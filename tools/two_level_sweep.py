@@ -19,7 +19,9 @@ tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
 prim = bench.city_camera(pa, blocks, side, 891379)
 first, _ = ctx.trace(torch.from_numpy(prim).to(dev))
 prim_id = tl.prim_ids_of(first["leaf"].cpu().numpy(), first["obj"].cpu().numpy())
-rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379)
+# SHUFFLE=0: the bounce rays in the order of the pixels that spawned them (what a wavefront integrator hands over) instead of shuffled
+rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379,
+                                     shuffle_seed=94892380 if os.environ.get("SHUFFLE", "1") == "1" else None)
 grid = int(os.environ.get("SORT_GRID", "0"))  # upper bound for ray reordering: the batch sorted on the host by origin cell (+ direction octant), sort not timed
 if grid:
     import numpy as np
