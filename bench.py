@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--city-blocks", type=int, default=24, help="two-level / sharded scene: city blocks per side (24 -> 11.4 M triangles)")
     ap.add_argument("--svdag-defer", type=int, default=0, help="two-level: SVDAG casts of passes with at least this many rays run as a kernel of their own (pgpu_set_svdag_defer; 0 = inside the episode, the default)")
+    ap.add_argument("--svdag-policy", choices=["always", "nonresident"], default="always",
+                    help="two-level / sharded: which batching points get the SVDAG early-out -- every one that has an SVDAG (the reference's behaviour) or only those whose geometry is not in this GPU's HBM (pgpu_set_svdag_policy 1; same hits)")
     ap.add_argument("--svdag", type=int, default=64, help="two-level / sharded scene: SVDAG resolution (0 = no proxy geometry, svdagRes 0 in the reference)")
     ap.add_argument("--sharded-side", type=int, default=4096, help="N > 1: primary image side per rank of the sharded record (batch ~ side^2 diffuse rays per rank)")
     ap.add_argument("--sharded-blocks", type=int, default=64, help="N > 1: city blocks per side of the sharded record's scene (64 -> 80.8 M triangles, 2048 batching points, ~10 GB of host memory per rank while building; 89 -> 156 M triangles, Moana's unique-triangle count, ~20 GB per rank)")
@@ -230,6 +232,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
     if args.svdag_defer:
         ctx.set_svdag_defer(args.svdag_defer, 2)
+    ctx.set_svdag_policy(1 if args.svdag_policy == "nonresident" else 0)
     stream = torch.cuda.current_stream().cuda_stream
     prim = city_camera(pa, args.city_blocks, args.side, 891379 + 7919 * rank)
     first, _ = ctx.trace(torch.from_numpy(prim).to(dev), stream=stream)
@@ -259,7 +262,9 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
             threads = max(1, min(16, os.cpu_count() or 1))
             sample = min(n, args.cpu_sample or (1 << 21))
             sub = np.ascontiguousarray(rays[:, :sample])
-            scene = ob.scene_from_two_level(tl, mesh)
+            import dataclasses
+            # (policy "nonresident" with every point resident: the oracle's scene without SVDAGs has the same visits and counters)
+            scene = ob.scene_from_two_level(tl if args.svdag_policy == "always" else dataclasses.replace(tl, dags=None), mesh)
             c0 = time.perf_counter()
             want = scene.trace(sub, any_hit=(args.kind == "any"), tri_mode=tri_mode, lanes=3, threads=threads)
             c1 = time.perf_counter()
@@ -268,7 +273,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
             cpu = {"value": sample / (c1 - c0) / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                    "sample": f"first {sample} rays of the same R-diffuse batch; PauseableBVH4::intersectT + SparseVoxelDAG::intersectScalar + WiVeBVH8::intersect restated in scalar C (oracle/pandora_oracle.c), {threads} pthreads",
                    "gpu_matches_bit_exact": bool(same)}
-        config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with %d^3 SVDAG early-out + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.svdag, args.kind),
+        config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with %d^3 SVDAG early-out%s + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.svdag, "" if args.svdag_policy == "always" else " for non-resident points only (here: none)", args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "batching_points": tl.n_leaves, "triangle_test": args.tri,
                   "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
@@ -391,6 +396,7 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
     sharded.comm_init(ctx, dev)  # RCCL communicator of the library's own; the unique id travels through torch.distributed
     ctx.comm_selftest()
     ctx.set_leaf_owners(owner)
+    ctx.set_svdag_policy(1 if args.svdag_policy == "nonresident" else 0)
     build_s = time.perf_counter() - t0
     prim = city_camera(pa, args.sharded_blocks, args.sharded_side, 891379 + 7919 * rank)
     first, _ = ctx.trace_sharded(torch.from_numpy(prim).to(dev))
@@ -424,7 +430,7 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
         total_rays, visits, routed, xbytes, ranks, resident, mesh_total = (float(x) for x in sums.tolist())
         el = float(mx.item())
         rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, %d^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (mesh.n_tris, tl.n_leaves, args.svdag, world),
-               "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
+               "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "svdag_policy": args.svdag_policy, "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
                "comm_selftest": "ok", "value": total_rays * steps / el / 1e6, "unit": "Mrays/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
                "rays_per_gpu": n, "rounds": cnt["rounds"], "leaf_visits_per_ray": visits / total_rays, "records_routed_per_step": routed,
                "records_routed_fraction": routed / max(1.0, visits), "exchange_bytes_per_step_all_ranks": xbytes,

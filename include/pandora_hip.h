@@ -196,6 +196,14 @@ int pgpu_set_leaf_hold(pgpu_ctx*, uint32_t image_bytes_per_ray);
 
 /* Shared SVDAG array + one descriptor per DAG (SparseVoxelDAG members, sparse_voxel_dag.h:70-78). */
 int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags);
+/* Which batching points get the SVDAG early-out. 0 (default) = every point that has an SVDAG, as the reference does
+ * (offline_batching_acceleration_structure.h:323-386). 1 = only the points whose geometry is not in this GPU's HBM -- staged in
+ * host memory (pgpu_stage_bvh8) or owned by another rank (PGPU_NO_BVH): the proxy test exists to save a load or a transfer, and
+ * a resident point is cheaper to visit than to test (11.4 M-triangle city, resident: 5.29 ms per step without the tests against
+ * 6.64 ms with them). Hits do not depend on the policy; pgpu_hits.visits and the SVDAG counters do. No counterpart in the
+ * reference, where every leaf visit may load from disk. */
+int pgpu_set_svdag_policy(pgpu_ctx*, int policy);
+
 /* Where pgpu_trace runs the SVDAG casts (same results either way, bit for bit; no counterpart in the reference, whose cast is
  * a call inside PauseableBVH4::intersectT, pauseable_bvh4.h:376-396). min_rays = 0 (the default): inside the top-level
  * episode kernel. min_rays > 0: passes of at least that many rays stop at every batching point that has a DAG, the cast

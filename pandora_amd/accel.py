@@ -413,6 +413,11 @@ class Context:
     def set_leaf_cache(self, n_bytes: int):
         _check(self._L.pgpu_set_leaf_cache(self._h, int(n_bytes)), self._h)
 
+    def set_svdag_policy(self, policy: int):
+        """0: every batching point with an SVDAG gets the early-out test (the reference). 1: only points whose geometry is not in
+        this GPU's HBM (staged or owned by another rank). Same hits; visits and SVDAG counters differ."""
+        _check(self._L.pgpu_set_svdag_policy(self._h, int(policy)), self._h)
+
     def set_leaf_hold(self, image_bytes_per_ray: int):
         """Streamed leaves: an image that is not in the cache is loaded once its batching point holds one ray per this many
         bytes of image; until then the point's rays stay parked (0 = never wait). Default 256."""

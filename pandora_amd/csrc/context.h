@@ -47,6 +47,8 @@ struct pgpu_ctx {
     DeviceBuffer spill;      // global overflow of the per-ray stacks
     unsigned char* staticScratch = nullptr; // this device's copy of the static scratch array of noalloc.hip (resolved at pgpu_init)
 
+    int svdagPolicy = 0;       // pgpu_set_svdag_policy: 0 = every batching point with an SVDAG is tested (the reference), 1 = only the points whose
+                               // geometry is not in this GPU's HBM (staged in host memory, or owned by another rank)
     uint32_t deferMin = 0;     // pgpu_set_svdag_defer: two-level passes of at least this many rays (0 = never) run their SVDAG casts as
     uint32_t deferPasses = 2;  // a kernel of their own this many times per round; the episode kernel finishes the rest with casts inside
     bool keepShading = false;  // uploads also keep the vertices per leaf object on the device (pgpu_set_keep_shading)

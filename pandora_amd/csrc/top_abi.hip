@@ -217,7 +217,11 @@ static int rebuildLeafDags(pgpu_ctx* c)
         LeafDagDev& r = ld[i];
         std::memset(&r, 0, sizeof(r));
         const uint32_t s = c->topLeavesHost[i].svdag;
-        if (s != PGPU_MISS_ID && s < c->dagsHost.size()) {
+        // pgpu_set_svdag_policy(ctx, 1): the proxy test exists to save a load; a point whose BVH sits in this GPU's
+        // HBM is cheaper to visit than to test
+        const uint32_t b = c->topLeavesHost[i].bvh;
+        const bool costly = b == PGPU_NO_BVH || (b < c->staged.size() && c->staged[b].host != nullptr);
+        if (s != PGPU_MISS_ID && s < c->dagsHost.size() && (c->svdagPolicy == 0 || costly)) {
             const SvdagDev& d = c->dagsHost[s];
             r.root = d.root;
             for (int a = 0; a < 3; ++a)
@@ -245,6 +249,15 @@ int pgpu_set_top_variant(pgpu_ctx* c, int variant, int refill_min, int cast_trip
     c->topRefillMin = refill_min ? uint32_t(refill_min) : 16u;
     c->topCastTrips = cast_trips ? uint32_t(cast_trips) : 4u;
     return PGPU_OK;
+}
+
+int pgpu_set_svdag_policy(pgpu_ctx* c, int policy)
+{
+    if (!c || policy < 0 || policy > 1)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_set_svdag_policy: 0 (test every batching point that has an SVDAG) or 1 (only points whose geometry is not resident here)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->svdagPolicy = policy;
+    return rebuildLeafDags(c);
 }
 
 int pgpu_set_svdag_defer(pgpu_ctx* c, uint32_t min_rays, uint32_t passes)

@@ -48,6 +48,7 @@ def main():
             sharded.comm_init(ctx, dev, host_staged=True)
             ctx.comm_selftest()
             ctx.set_leaf_owners(owner)
+            ctx.set_svdag_policy(int(os.environ.get("PANDORA_TEST_SVDAG_POLICY", "0")))
             st, cnt = ctx.trace_sharded(d_rays, kind=kind)
             info = {"routed": cnt["records_routed"], "rounds": cnt["rounds"], "leaf_visits": cnt["leaf_visits"]}
             film = torch.full((5, 3), rank + 1, dtype=torch.int64, device=dev)

@@ -140,6 +140,33 @@ def test_two_processes_sharded_leaves(scene, kind, device_records):
     assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
 
 
+def test_two_processes_sharded_svdag_only_for_remote_points(scene):
+    """pgpu_set_svdag_policy(ctx, 1) on two ranks: a rank tests the SVDAG of the other rank's batching points (a miss saves a
+    record's round trip) and visits its own without the test. Same hits as one context; fewer SVDAG tests."""
+    ctx, mesh, tl = scene
+    rays = _rays(mesh)
+    want, wcnt = ctx.trace(rays)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "rays.npy"), rays)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PANDORA_TEST_SVDAG_POLICY="1")
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(pa.capi.CLOSEST), "2"], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+        parts = [dict(np.load(os.path.join(d, f"r{r}.npz"))) for r in range(2)]
+    for r, p in enumerate(parts):
+        for k in ("t", "obj", "leaf", "u", "v"):
+            assert np.array_equal(_bits(p[k]), _bits(want[k])[r::2]), f"rank {r}: {k}"
+    tests = sum(int(p["svdag_tests"]) for p in parts)
+    assert 0 < tests < wcnt["svdag_tests"]
+    assert sum(int(p["leaf_visits"]) for p in parts) >= wcnt["leaf_visits"]
+
+
 def test_four_processes_sharded_city():
     """Four ranks (sharing the one GPU, records through host memory) on a city of ~60 batching points, each rank building and
     uploading only its own points' BVHs and triangles, 150 K shuffled diffuse rays: several rounds with thousands of records

@@ -66,6 +66,14 @@ def test_streamed_leaves_match_resident(svdag, copy_mode, hold):
             if budget and budget < 4 * slot and hold == 0:
                 assert cnt["leaf_loads"] > budget // slot, f"{label}: more BVHs were needed than fit, so space must have been recycled (loads {cnt['leaf_loads']})"
             assert cnt["streamed_bytes"] >= cnt["leaf_loads"] * 256 or cnt["leaf_loads"] == 0
+    # pgpu_set_svdag_policy(ctx, 1) keeps the proxy test for points whose geometry is not in HBM: here that is every point
+    ctx.set_leaf_cache(0)
+    ctx.set_svdag_policy(1)
+    got, cnt = ctx.trace(rays)
+    exp, ecnt = want[pa.capi.CLOSEST]
+    for k in ("t", "obj", "leaf", "u", "v", "visits"):
+        assert np.array_equal(_bits(got[k]), _bits(exp[k])), f"policy 1: {k}"
+    assert cnt["svdag_tests"] == ecnt["svdag_tests"] and cnt["svdag_culled"] == ecnt["svdag_culled"]
     with pytest.raises(pa.capi.PandoraError):
         ctx.set_leaf_cache(64)
         ctx.trace(rays)

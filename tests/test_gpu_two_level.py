@@ -155,3 +155,34 @@ def test_regrouped_mesh_upload_matches_whole_mesh(two_level):
     for k in ("t", "obj", "leaf", "u", "v", "visits"):
         assert np.array_equal(_bits(got[k]), _bits(want[k])), k
     assert cnt["leaf_visits"] == wcnt["leaf_visits"]
+
+
+def test_svdag_policy_skips_the_test_for_resident_points(two_level):
+    """pgpu_set_svdag_policy(ctx, 1): batching points whose BVH is in HBM are visited without the proxy test. With every point
+    resident that is the scene without SVDAGs -- same hits as with them, the visit counts and counters of the oracle's scene
+    without DAGs."""
+    import dataclasses
+    ctx, mesh, tl, orc = two_level
+    bare = ob.scene_from_two_level(dataclasses.replace(tl, dags=None), mesh)
+    rays = _ray_sets(mesh)["diffuse"]
+    ctx.set_ray_layout(0)
+    ctx.set_kernel_variant(0, 0, 0)
+    ref, _ = ctx.trace(rays)
+    ctx.set_svdag_policy(1)
+    try:
+        got, cnt = ctx.trace(rays)
+        got_any, cnt_any = ctx.trace(rays, kind=pa.capi.ANY)
+    finally:
+        ctx.set_svdag_policy(0)
+    want = bare.trace(rays, lanes=3)
+    for k in ("t", "obj", "leaf", "u", "v", "visits"):
+        assert np.array_equal(_bits(got[k]), _bits(want[k])), k
+    for k in ("t", "obj", "leaf", "u", "v"):
+        assert np.array_equal(_bits(got[k]), _bits(ref[k])), f"{k}: the hits must not depend on the policy"
+    assert cnt["svdag_tests"] == 0 and cnt["leaf_visits"] == want["counters"]["leaf_visits"]
+    want_any = bare.trace(rays, any_hit=True, lanes=3)
+    assert np.array_equal(_bits(got_any["hit"]), want_any["hit"]) and np.array_equal(_bits(got_any["visits"]), want_any["visits"])
+    again, cnt2 = ctx.trace(rays)  # back to the reference's behaviour
+    assert np.array_equal(_bits(again["visits"]), _bits(ref["visits"]))
+    if tl.dags is not None:
+        assert cnt2["svdag_tests"] > 0

@@ -73,8 +73,9 @@ def timed_more():
 
 
 print("checksum", {k: float(v.double().sum()) for k, v in out.items() if torch.is_tensor(v)}, flush=True)
-settings = [dict(), dict()]
+settings = [dict(), dict(), dict(pol=1)]
 for s in settings:
+    ctx.set_svdag_policy(s.get("pol", 0))  # 1: SVDAG early-out only for batching points that are not resident
     ctx.set_ray_layout(s.get("lanes", 0))
     ctx.set_round_lookahead(bool(s.get("look", 1)))
     ctx.set_top_variant(s.get("top", 1), s.get("trefill", 0), s.get("trips", 0))
