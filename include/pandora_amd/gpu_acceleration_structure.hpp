@@ -83,6 +83,10 @@ struct AdapterOptions {
     // batching point's BVH is resident in HBM; otherwise the BVHs stay in pinned host memory and are streamed through an HBM
     // cache of this size (pgpu_stage_bvh8 / pgpu_set_leaf_cache; it must hold the largest one). Not with LeafSharded.
     size_t botLevelBVHCacheBytes = 0;
+    // pgpu_set_svdag_policy(ctx, 1): the SVDAG early-out only for batching points whose geometry is not in the GPU's HBM (streamed
+    // from host memory, or owned by another GPU); resident points are visited directly. Same hits; Ray::numTopLevelIntersections
+    // and the SVDAG counters differ from the reference's.
+    bool svdagOnlyForNonResident = false;
 };
 
 inline void check(int rc, pgpu_ctx* ctx, const char* what)
@@ -956,6 +960,9 @@ public:
         if (hs)
             pgpu_host_svdags_free(hs);
         check(rc, failedCtx, failedWhat);
+        if (m_options.svdagOnlyForNonResident)
+            for (size_t d = 0; d < nDev; ++d)
+                check(pgpu_set_svdag_policy(m.devices[d].ctx, 1), m.devices[d].ctx, "pgpu_set_svdag_policy");
         if (m.sharded) {
             joinCommunicator(m.devices, m.exchange);
             for (size_t d = 0; d < nDev; ++d) // (the owner table is checked against the communicator's size)

@@ -246,7 +246,18 @@ static int multi()
     } catch (const std::exception&) {
         refused = true;
     }
-    if (!okS || !okS2 || !refused)
+    // SVDAG early-out only for non-resident points: with everything resident no test runs; the hits stay what they were
+    AdapterOptions direct = one;
+    direct.svdagOnlyForNonResident = true;
+    const Outcome dr = runScene(shapes, direct, n, 4);
+    const bool okD = dr.shape == a.shape && dr.prim == a.prim && dr.tBits == a.tBits && dr.shadow == a.shadow && dr.nz == a.nz && dr.traced == a.traced
+        && dr.counters.svdag_tests == 0 && dr.counters.leaf_visits >= a.counters.leaf_visits;
+    std::printf("one context, SVDAG test for non-resident points only: %s (svdag tests %llu, leaf visits %llu)\n", okD ? "same hits" : "DIFFERENT",
+        (unsigned long long)dr.counters.svdag_tests, (unsigned long long)dr.counters.leaf_visits);
+    AdapterOptions directStreamed = streamed; // ... and streamed points keep their test: everything as in the reference
+    directStreamed.svdagOnlyForNonResident = true;
+    const bool okDS = same(runScene(shapes, directStreamed, n, 4), "one context, streamed, SVDAG test for non-resident points only");
+    if (!okS || !okS2 || !refused || !okD || !okDS)
         return 1;
     if (hits < size_t(n) / 2 || shadowed == 0 || shadowed == hits || !okB || !okC || !okR || c.counters.records_routed == 0)
         return 1;
