@@ -193,6 +193,50 @@ def test_config2_two_level_11M_triangles_svdag64():
         ctx.close()
 
 
+@pytest.mark.timeout(600)
+def test_config4_instanced_landscape_50k_instances_resident_and_streamed():
+    """One GPU's part of configs[4] at a size where the oracle takes seconds: 50 000 instances of 32 tree prototypes (1.3 x 10^8
+    instanced triangles) on a 131 K-triangle terrain, ~100 batching points cut over the scene's objects. Primary rays and their
+    diffuse bounces (normals of instanced hits through the instance's matrix): resident (rounds queued ahead, ray records) and
+    streamed through a cache of a fifth of the images with waiting rays -- hits, the instance of every hit, visit counts
+    and counters equal the oracle's, bit for bit."""
+    torch = _need_gpu()
+    n_inst, size = 50_000, float((50_000 * 64.0) ** 0.5)
+    terrain, protos, proto, mats = pa.scenes.g_landscape(n_prototypes=32, n_instances=n_inst, terrain_n=256, size=size, detail=2)
+    tl = pa.accel.build_instanced_two_level(terrain.pos, terrain.idx, [(p.pos, p.idx) for p in protos], proto, mats, 16384, svdag_res=0)
+    assert tl.n_leaves >= 64
+    scene = ob.scene_from_instanced(tl)
+    prim = pa.scenes.primary_rays((0.35 * size, 0.06 * size, 0.35 * size), (0.65 * size, 0.0, 0.65 * size), (0, 1, 0), 60, 512, 512)
+    first = scene.trace(prim, threads=THREADS)
+    assert 0.02 < (first["inst"] != MISS).mean() < 0.9
+    normals = tl.hit_normals(first["leaf"], first["obj"], first["inst"])
+    diff = pa.scenes.diffuse_bounce_rays(None, prim, first["t"], first["obj"].view(np.uint32), normals=normals)
+    want = {name: {kind: scene.trace(rays, any_hit=(kind == pa.capi.ANY), threads=THREADS) for kind in (pa.capi.CLOSEST, pa.capi.ANY)}
+            for name, rays in (("primary", prim), ("diffuse", diff))}
+    image = [b.n_nodes * 256 + (b.leaf_idx.size + 1) * 48 + 64 * gi.size + 1024 for b, gi in zip(tl.bvhs, tl.group_insts)]
+    for streamed in (False, True):
+        ctx = pa.accel.Context(0)
+        try:
+            tl.upload(ctx, streamed=streamed)
+            if streamed:
+                ctx.set_leaf_cache(max(2 * max(image), sum(image) // 5))
+            for name, rays in (("primary", prim), ("diffuse", diff)):
+                d_rays = torch.from_numpy(rays).cuda()
+                for kind in (pa.capi.CLOSEST, pa.capi.ANY):
+                    got, cnt = ctx.trace(d_rays, kind=kind)
+                    exp = want[name][kind]
+                    for k in (("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits", "inst")):
+                        bad = int((_bits(got[k]) != _bits(exp[k])).sum())
+                        assert bad == 0, f"streamed {streamed} {name} kind {kind} {k}: {bad} of {rays.shape[1]} rays differ"
+                    assert cnt["leaf_visits"] == exp["counters"]["leaf_visits"]
+                    if streamed:
+                        assert cnt["leaf_loads"] > 0 and cnt["rounds"] >= int(exp["visits"].max())
+                    else:
+                        assert cnt["rounds"] == int(exp["visits"].max())
+        finally:
+            ctx.close()
+
+
 # ------------------------------------------------------------------------------------------------ D1 / N3 on the GPU
 def test_bvh8_file_to_gpu_equals_golden(gpu_ctx):
     """bvh8_to_bytes -> bvh8_from_bytes -> upload -> trace reproduces the golden vectors, for the dense array our writer
