@@ -704,10 +704,13 @@ class TwoLevelScene:
         """Mesh triangle id of every hit record (leaf slot, leaf-object index); MISS stays MISS."""
         leaf, obj = np.asarray(leaf).view(np.uint32), np.asarray(obj).view(np.uint32)
         out = np.full(obj.shape, capi.MISS, np.uint32)
-        hit = obj != np.uint32(capi.MISS)
-        for l in np.unique(leaf[hit]):
-            m = hit & (leaf == l)
-            out[m] = self.groups[int(self.top.leaf_order[int(l)])][obj[m]]  # (leaf object j of a point = its j-th triangle)
+        hit = np.nonzero(obj != np.uint32(capi.MISS))[0]
+        # (leaf object j of a point = its j-th triangle) -- one gather through the groups laid end to end
+        sizes = np.array([g.size for g in self.groups], np.int64)
+        start = np.concatenate([[0], np.cumsum(sizes)])
+        cat = np.concatenate(self.groups) if self.groups else np.zeros(0, np.uint32)
+        group = np.asarray(self.top.leaf_order, np.int64)[leaf[hit].astype(np.int64)]
+        out[hit] = cat[start[group] + obj[hit].astype(np.int64)]
         return out
 
     def device_bytes(self, n_verts: int = 0) -> int:
