@@ -701,7 +701,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         for (size_t r = 0; r + 4 < c->roundCountsCap; ++r) {
             uint32_t* const countOut = dParkedCount + (r & 1u);
             const uint32_t* const countIn = r ? dParkedCount + ((r - 1) & 1u) : nullptr;
-            HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
+            if (r == 0) // (later rounds: the scan of the round before left the counts zeroed)
+                HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
             ta.active = active;
             ta.n_active = bound;
             ta.n_active_dev = countIn;
@@ -714,7 +715,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ta.only_culled = 0u;
             const uint32_t listBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (bound + 255u) / 256u));
             HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (bound + 255u) / 256u)), stream));
-            HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), countOut, stream));
+            HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), countOut, stream, dLeafCount, c->cursor));
             // The parked rays by batching point, for the bottom level (binning). The next top-level episode takes the same list when
             // its waves run in lockstep -- rays of one batching point walk the same nodes and cast through the same DAG -- and the
             // parked rays in the order of the current list, i.e. by ascending ray id, when its lanes are independent anyway
@@ -730,7 +731,6 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             }
             HIP_TRY(c, hipMemcpyAsync(&c->roundCounts[r], countOut, 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(c, hipEventRecord(c->roundEv[r & 1u], stream));
-            HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
             ba.work_ray = workRayOut;
             ba.n_work = bound;
             ba.n_work_dev = countOut;

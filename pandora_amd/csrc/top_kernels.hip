@@ -793,9 +793,13 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(4, 8)
 }
 
 // exclusive scan of leaf_count into leaf_start (single block; batching points number in the hundreds)
-__global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
-    uint32_t* __restrict__ fill, uint32_t n, uint32_t* __restrict__ total)
+// (resetCount / cursor: rounds queued ahead of the host -- the scan leaves the counts zeroed for the next episode and clears the
+// bottom-level kernel's work cursors, which saves two fill launches per round; the tail of a trace is a string of tiny rounds)
+__global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* count, uint32_t* __restrict__ start,
+    uint32_t* __restrict__ fill, uint32_t n, uint32_t* __restrict__ total, uint32_t* resetCount = nullptr /* may be `count` */, uint32_t* __restrict__ cursor = nullptr)
 {
+    if (cursor && threadIdx.x < 64u)
+        cursor[threadIdx.x] = 0u;
     __shared__ uint32_t part[1024];
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t lo = min(threadIdx.x * per, n), hi = min(lo + per, n);
@@ -814,7 +818,10 @@ __global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* __restric
     for (uint32_t i = lo; i < hi; ++i) {
         start[i] = run;
         fill[i] = 0;
-        run += count[i];
+        const uint32_t c = count[i];
+        run += c;
+        if (resetCount)
+            resetCount[i] = 0u;
     }
     if (threadIdx.x == 1023)
         *total = part[1023]; // rays parked in this round
@@ -1093,9 +1100,10 @@ hipError_t launchSvdagCast(const CastArgs& a, uint32_t blocks, hipStream_t strea
     return hipGetLastError();
 }
 
-hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream)
+hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream, uint32_t* resetCount,
+    uint32_t* cursor64)
 {
-    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, count, start, fill, n, total);
+    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, count, start, fill, n, total, resetCount, cursor64);
     return hipGetLastError();
 }
 
@@ -1117,7 +1125,7 @@ hipError_t launchCompactParked(const uint32_t* active, const uint32_t* parkedLea
     uint32_t* sliceStart, uint32_t* scratchFill, uint32_t* scratchTotal, uint32_t* nextActive, uint32_t slices, hipStream_t stream)
 {
     hipLaunchKernelGGL(compactCountKernel, dim3(slices), dim3(256), 0, stream, parkedLeaf, n, nDev, nLeaves, sliceCount);
-    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, sliceCount, sliceStart, scratchFill, slices, scratchTotal);
+    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, sliceCount, sliceStart, scratchFill, slices, scratchTotal, (uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(compactWriteKernel, dim3(slices), dim3(256), 0, stream, active, parkedLeaf, n, nDev, nLeaves, sliceStart, nextActive);
     return hipGetLastError();
 }
