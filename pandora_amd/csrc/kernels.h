@@ -179,9 +179,10 @@ hipError_t launchSvdagCast(const CastArgs& a, uint32_t blocks, hipStream_t strea
 hipError_t launchSvdagPlan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t* unitStart, uint32_t n, uint32_t* plan, hipStream_t stream);
 size_t svdagCastLdsBytes(const TopDev& top);
 size_t topTraverseLdsBytes(const TopDev& top);
-// resetCount (= count, or null): the counts are zeroed once they have been scanned; cursor64 (or null): 64 words cleared as well
+// resetCount (= count, or null): the counts are zeroed once they have been scanned; cursor64 (or null): 64 words cleared as well;
+// totalHost (or null): pinned host memory that receives the total too
 hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream,
-    uint32_t* resetCount = nullptr, uint32_t* cursor64 = nullptr);
+    uint32_t* resetCount = nullptr, uint32_t* cursor64 = nullptr, uint32_t* totalHost = nullptr);
 // requests = true: bins the positions whose parked_leaf carries kCastRequestFlag (by the batching point under the flag)
 hipError_t launchBinByLeaf(const uint32_t* active, const uint32_t* parkedLeaf, uint32_t nActive, uint32_t nLeaves, const uint32_t* leafStart,
     uint32_t* leafFill, const TopLeafDev* leaves, uint32_t* workRay, uint32_t* workBvh, uint32_t* workLeaf, uint32_t blocks, hipStream_t stream,

@@ -715,7 +715,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ta.only_culled = 0u;
             const uint32_t listBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (bound + 255u) / 256u));
             HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (bound + 255u) / 256u)), stream));
-            HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), countOut, stream, dLeafCount, c->cursor));
+            HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), countOut, stream, dLeafCount, c->cursor, &c->roundCounts[r]));
             // The parked rays by batching point, for the bottom level (binning). The next top-level episode takes the same list when
             // its waves run in lockstep -- rays of one batching point walk the same nodes and cast through the same DAG -- and the
             // parked rays in the order of the current list, i.e. by ascending ray id, when its lanes are independent anyway
@@ -729,8 +729,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 HIP_TRY(c, launchCompactParked(active, dParkedLeaf, bound, countIn, uint32_t(nl), dSliceCount, dSliceStart, dSliceFill, dParkedCount + 8,
                                nextActive, std::max(1u, std::min(4096u, (bound + 1023u) / 1024u)), stream));
             }
-            HIP_TRY(c, hipMemcpyAsync(&c->roundCounts[r], countOut, 4, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipEventRecord(c->roundEv[r & 1u], stream));
+            HIP_TRY(c, hipEventRecord(c->roundEv[r & 1u], stream)); // (the scan wrote the round's count to roundCounts[r], pinned)
             ba.work_ray = workRayOut;
             ba.n_work = bound;
             ba.n_work_dev = countOut;

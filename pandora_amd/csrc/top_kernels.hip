@@ -796,7 +796,8 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(4, 8)
 // (resetCount / cursor: rounds queued ahead of the host -- the scan leaves the counts zeroed for the next episode and clears the
 // bottom-level kernel's work cursors, which saves two fill launches per round; the tail of a trace is a string of tiny rounds)
 __global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* count, uint32_t* __restrict__ start,
-    uint32_t* __restrict__ fill, uint32_t n, uint32_t* __restrict__ total, uint32_t* resetCount = nullptr /* may be `count` */, uint32_t* __restrict__ cursor = nullptr)
+    uint32_t* __restrict__ fill, uint32_t n, uint32_t* __restrict__ total, uint32_t* resetCount = nullptr /* may be `count` */, uint32_t* __restrict__ cursor = nullptr,
+    uint32_t* __restrict__ totalHost = nullptr /* pinned host memory: the same total, without a copy of its own */)
 {
     if (cursor && threadIdx.x < 64u)
         cursor[threadIdx.x] = 0u;
@@ -823,8 +824,11 @@ __global__ __launch_bounds__(1024) void leafScanKernel(const uint32_t* count, ui
         if (resetCount)
             resetCount[i] = 0u;
     }
-    if (threadIdx.x == 1023)
+    if (threadIdx.x == 1023) {
         *total = part[1023]; // rays parked in this round
+        if (totalHost)
+            *totalHost = part[1023];
+    }
 }
 
 // scatter parked records into per-leaf contiguous ranges (the GPU form of the per-leaf queues)
@@ -1101,9 +1105,9 @@ hipError_t launchSvdagCast(const CastArgs& a, uint32_t blocks, hipStream_t strea
 }
 
 hipError_t launchLeafScan(const uint32_t* count, uint32_t* start, uint32_t* fill, uint32_t n, uint32_t* total, hipStream_t stream, uint32_t* resetCount,
-    uint32_t* cursor64)
+    uint32_t* cursor64, uint32_t* totalHost)
 {
-    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, count, start, fill, n, total, resetCount, cursor64);
+    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, count, start, fill, n, total, resetCount, cursor64, totalHost);
     return hipGetLastError();
 }
 
@@ -1125,7 +1129,7 @@ hipError_t launchCompactParked(const uint32_t* active, const uint32_t* parkedLea
     uint32_t* sliceStart, uint32_t* scratchFill, uint32_t* scratchTotal, uint32_t* nextActive, uint32_t slices, hipStream_t stream)
 {
     hipLaunchKernelGGL(compactCountKernel, dim3(slices), dim3(256), 0, stream, parkedLeaf, n, nDev, nLeaves, sliceCount);
-    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, sliceCount, sliceStart, scratchFill, slices, scratchTotal, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(leafScanKernel, dim3(1), dim3(1024), 0, stream, sliceCount, sliceStart, scratchFill, slices, scratchTotal, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(compactWriteKernel, dim3(slices), dim3(256), 0, stream, active, parkedLeaf, n, nDev, nLeaves, sliceStart, nextActive);
     return hipGetLastError();
 }
