@@ -199,8 +199,8 @@ int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const p
 /* Which batching points get the SVDAG early-out. 0 (default) = every point that has an SVDAG, as the reference does
  * (offline_batching_acceleration_structure.h:323-386). 1 = only the points whose geometry is not in this GPU's HBM -- staged in
  * host memory (pgpu_stage_bvh8) or owned by another rank (PGPU_NO_BVH): the proxy test exists to save a load or a transfer, and
- * a resident point is cheaper to visit than to test (11.4 M-triangle city, resident: 5.29 ms per step without the tests against
- * 6.64 ms with them). Hits do not depend on the policy; pgpu_hits.visits and the SVDAG counters do. No counterpart in the
+ * a resident point is cheaper to visit than to test (11.4 M-triangle city, resident: 5.2 ms per step without the tests against
+ * 6.6 ms with them). Hits do not depend on the policy; pgpu_hits.visits and the SVDAG counters do. No counterpart in the
  * reference, where every leaf visit may load from disk. */
 int pgpu_set_svdag_policy(pgpu_ctx*, int policy);
 
