@@ -74,6 +74,8 @@ def timed_more():
 
 print("checksum", {k: float(v.double().sum()) for k, v in out.items() if torch.is_tensor(v)}, flush=True)
 settings = [dict(), dict(), dict(pol=1)]
+if os.environ.get("SWEEP", "0") == "1":
+    settings = [dict()] + [dict(chunk=c) for c in (32, 64, 256)] + [dict(refill=r) for r in (3, 4, 8, 12)] + [dict(leaf=l) for l in (4, 6, 12, 16)] + [dict(bpc=b) for b in (3, 5)] + [dict()]
 for s in settings:
     ctx.set_svdag_policy(s.get("pol", 0))  # 1: SVDAG early-out only for batching points that are not resident
     ctx.set_ray_layout(s.get("lanes", 0))
