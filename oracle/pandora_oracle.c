@@ -1047,8 +1047,10 @@ void orc_camera_rays(const orc_camera* cam, uint32_t width, uint32_t height, uin
     }
 }
 
-static void dead_ray(float* rays, size_t n, size_t k)
+/* a path that ended (miss: path_integrator.cpp:113-127, failed bounce: :109-112): unhittable ray, weight zero -- it contributes nothing more */
+static void dead_ray(float* rays, const orc_paths* paths, size_t n, size_t k)
 {
+    paths->wr[k] = paths->wg[k] = paths->wb[k] = 0.0f;
     for (int a = 0; a < 6; a++)
         rays[(size_t)a * n + k] = a == 3 ? 1.0f : 0.0f;
     rays[6 * n + k] = 1.0f;
@@ -1061,7 +1063,7 @@ void orc_lambert_bounce(const orc_bvh8* b1, const orc_scene* s, const float* ray
     (void)t;
     for (size_t k = 0; k < n; k++) {
         if (obj[k] == ORC_MISS) {
-            dead_ray(rays, n, k);
+            dead_ray(rays, paths, n, k);
             continue;
         }
         const orc_bvh8* b = b1 ? b1 : &s->leaves[leaf[k]].bvh;
@@ -1129,7 +1131,7 @@ void orc_lambert_bounce(const orc_bvh8* b1, const orc_scene* s, const float* ray
         paths->rng_state[k] = nst;
         paths->rng_inc[k] = ninc;
         if (!(pdf > 0.0f) || (albedo[0] == 0.0f && albedo[1] == 0.0f && albedo[2] == 0.0f)) {
-            dead_ray(rays, n, k);
+            dead_ray(rays, paths, n, k);
             continue;
         }
         /* weight = prev * f * absDot(wi, ns) / pdf with f = albedo / pi (:152) */

@@ -105,8 +105,14 @@ struct BounceArgs {
     pgpu_paths paths;
 };
 
-__device__ __forceinline__ void deadRay(const pgpu_rays_out& r, uint32_t k)
+// A path that ended (it missed -- its sky contribution was added when the miss was splatted, path_integrator.cpp:113-127 -- or
+// its bounce failed, :109-112): a ray that cannot hit anything AND a weight of zero, so that the miss of the dead ray adds nothing
+// when the next depth is splatted. The reference ends the path; here its slot stays in the batch.
+__device__ __forceinline__ void deadRay(const pgpu_rays_out& r, const pgpu_paths& p, uint32_t k)
 {
+    p.wr[k] = 0.0f;
+    p.wg[k] = 0.0f;
+    p.wb[k] = 0.0f;
     r.ox[k] = 0.0f;
     r.oy[k] = 0.0f;
     r.oz[k] = 0.0f;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void lambertBounceKernel(BounceArgs a)
         }
         const float* shade = (obj != PGPU_MISS_ID && bvhId < a.nBvhs) ? a.bvhs[bvhId].shade : nullptr;
         if (!shade) {
-            deadRay(a.rays, k);
+            deadRay(a.rays, a.paths, k);
             continue;
         }
         const float* tp = shade + size_t(obj) * 9u;
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void lambertBounceKernel(BounceArgs a)
         a.paths.rng_state[k] = nst;
         a.paths.rng_inc[k] = ninc;
         if (!(pdf > 0.0f) || (a.albedo[0] == 0.0f && a.albedo[1] == 0.0f && a.albedo[2] == 0.0f)) {
-            deadRay(a.rays, k);
+            deadRay(a.rays, a.paths, k);
             continue;
         }
         const float adot = fabsf(dot(wi, ng));

@@ -86,9 +86,16 @@ def test_camera_bounce_splat_single_level():
             if depth == 0:
                 _check_bounce(rays_next, paths, want_next, want_paths, "first bounce")
                 hit = want_hits["obj"] != ob.MISS
+                first_miss = ~hit
                 assert hit.mean() > 0.8 and np.array_equal(_np(rays_next)[6] > _np(rays_next)[7], ~hit)
+            # an ended path (miss, failed bounce) keeps its slot but not its weight: it adds nothing at the later depths
+            dead = _np(rays_next)[6] > _np(rays_next)[7]
+            assert dead.any() and all((_np(paths[k])[dead] == 0.0).all() for k in ("wr", "wg", "wb"))
             rays, want_rays = rays_next, want_next
         assert np.count_nonzero(want_film) > 100
+        # a pixel whose samples all missed at depth 0 holds spp x sky exactly once each (path_integrator.cpp:113-127), not once per depth
+        both = first_miss.reshape(-1, spp).all(axis=1)
+        assert both.any() and np.allclose(ob.film_resolve(_np(film).view(np.uint64))[both], np.float32(spp) * np.array(sky, np.float32), rtol=1e-6)
     finally:
         ctx.close()
 
