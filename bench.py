@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded record")
     ap.add_argument("--sharded-timeout", type=int, default=420, help="seconds after which the sharded record is given up and the line printed without it")
     ap.add_argument("--force-sharded", action="store_true", help="N = 1: run the sharded record too (one rank owns every batching point; rehearsal of the N > 1 path)")
+    ap.add_argument("--no-two-level", action="store_true", help="N = 1, --config single: skip the `two_level` sub-record (configs[2], timed after the headline)")
+    ap.add_argument("--two-level-steps", type=int, default=10, help="timed steps of the `two_level` sub-record")
     ap.add_argument("--dry", action="store_true", help="no GPU: the ranks only meet (gloo) and reduce made-up figures; checks the launch path")
     return ap.parse_args()
 
@@ -194,18 +196,19 @@ def run_single(args, pa, torch, ctx, dev, rank):
                    "traversal_model_bytes_per_ray": 256.0 * vpr["inner_visits"] + 4.0 * vpr["tri_tests"] + 48.0 * vpr["tri_tests"]}
         # HBM-side bytes per launch of the dominant kernel come from rocprofv3 PMC passes of this same command
         # (tools/pmc_passes.sh), which cannot run inside the timed process; the committed summary is quoted.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, issue = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if args.rays == "diffuse" and args.kind == "closest" and args.tri == "moller-trumbore" and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("rays_per_launch") == n:
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/pmc_traffic.json (" + tj["how"] + ")"
+                issue = tj.get("issue")  # what actually bounds the kernel: VALU issue slots used, lanes active, waves waiting (same PMC passes)
         config = {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-%s %s-hit" % (mesh.n_tris, args.rays, args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
                   "triangle_test": args.tri, "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": traffic_src, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
+                    "traffic": traffic, "traffic_source": traffic_src, "issue": issue, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "scene_bytes": scene_bytes}
         if cpu is not None:
             roofline["traversal_model_GBps"] = cpu["traversal_model_bytes_per_ray"] * n / (k_ms * 1e-3) / 1e9
@@ -279,15 +282,16 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         # memory-side bytes per step from rocprofv3 PMC passes of this same command (tools/pmc_two_level_traffic.py), quoted as for
         # the single-level config: counters cannot be read from inside the timed process
-        traffic, traffic_src = None, None
+        traffic, traffic_src, issue = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_two_level.json")
-        if args.kind == "closest" and args.tri == "moller-trumbore" and args.svdag == 64 and os.path.exists(tpath):
+        if args.kind == "closest" and args.tri == "moller-trumbore" and args.svdag == 64 and args.svdag_policy == "always" and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("rays_per_step") == n:
                 traffic, traffic_src = tj["traffic_bytes_per_step"], "profiles/pmc_traffic_two_level.json (" + tj["how"] + ")"
+                issue = tj.get("issue")
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": traffic_src,
+                    "traffic_source": traffic_src, "issue": issue,
                     "kernel": "the round loop (topTraverseKernel + leafScan / binByLeaf + bvh8TracePairKernel, all rounds), device time between the loop's first and last event",
                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_ray": per_ray, "bytes_per_leaf_visit": 88, "scene_bytes": scene_bytes}
         return config, roofline, cpu
@@ -478,56 +482,93 @@ def main() -> int:
                   "ranks_seen": [int(i) for i in torch.nonzero(seen).flatten().tolist()], "steps": args.steps, "warmup": args.warmup})
         if world > 1:
             dist.destroy_process_group()
-        return 0
+        # (test hook: a rank that fails after the line is out -- the launcher must hand its status on, tests/test_bench_launch.py)
+        return 3 if os.environ.get("PANDORA_BENCH_DRY_FAIL_RANK") == str(rank) else 0
 
     import pandora_amd as pa
+    from pandora_amd.sharded import reduce_job
 
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+
+    def timed(ctx, step, steps, warmup):
+        """W untimed steps, then exactly `steps` between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            # per-launch kernel time from HIP events recorded by the library on this same stream; reading
+            # them needs the step to have finished, which also keeps one batch in flight at a time
+            ctx.sync(torch.cuda.current_stream().cuda_stream)
+            kernel_ms.append(ctx.last_kernel_ms())
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, float(np.mean(kernel_ms))
+
     ctx = pa.accel.Context(dev.index)
     step, n, finish = {"single": run_single, "two-level": run_two_level, "landscape": run_landscape}[args.config](args, pa, torch, ctx, dev, rank)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # per-launch kernel time from HIP events recorded by the library on this same stream; reading
-        # them needs the step to have finished, which also keeps one batch in flight at a time
-        ctx.sync(torch.cuda.current_stream().cuda_stream)
-        kernel_ms.append(ctx.last_kernel_ms())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    from pandora_amd.sharded import reduce_job
+    elapsed, k_ms = timed(ctx, step, args.steps, args.warmup)
     elapsed, total_rays = reduce_job(elapsed, n, dev)  # max over ranks, rays summed over ranks
 
     line = None
+    failed = False
     if rank == 0:
-        k_ms = float(np.mean(kernel_ms))
         config, roofline, cpu = finish(k_ms, world)
         line = {"metric": "Mrays/s incoherent diffuse rays", "value": total_rays * args.steps / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roofline, "cpu_baseline": cpu}
+        if cpu is not None and not cpu.get("gpu_matches_bit_exact", True):
+            failed = True
     ctx.close()
+    del step, finish
+
+    if world == 1 and args.config == "single" and not args.no_two_level:
+        # configs[2] in the same line: the reference's actual hot path (offline_batching...h:406-437, pauseable_bvh4.h:225-355) --
+        # PauseableBVH4 + SVDAG early-out + per-point BVH8, the whole round loop per step -- timed after the headline on a
+        # context of its own, with its own roofline and CPU baseline. The headline above is not touched by it.
+        t_sub = time.perf_counter()
+        try:
+            import copy
+            a2 = copy.copy(args)
+            a2.kind, a2.tri, a2.rays, a2.cpu_sample = "closest", "moller-trumbore", "diffuse", 0
+            ctx2 = pa.accel.Context(dev.index)
+            step2, n2, finish2 = run_two_level(a2, pa, torch, ctx2, dev, rank)
+            steps2 = max(1, args.two_level_steps)
+            el2, k2 = timed(ctx2, step2, steps2, 2)
+            config2, roofline2, cpu2 = finish2(k2, world)
+            ctx2.close()
+            line["two_level"] = {"value": n2 * steps2 / el2 / 1e6, "unit": "Mrays/s", "steps": steps2, "warmup": 2, "ms_per_step": 1e3 * el2 / steps2,
+                                 "config": config2, "roofline": roofline2, "cpu_baseline": cpu2,
+                                 "gpu_matches_bit_exact": None if cpu2 is None else cpu2["gpu_matches_bit_exact"],
+                                 "wall_s_including_scene_build": None}
+            line["two_level"]["wall_s_including_scene_build"] = time.perf_counter() - t_sub
+            if cpu2 is not None and not cpu2["gpu_matches_bit_exact"]:
+                failed = True
+        except Exception as e:  # the headline still goes out, the exit status says that the sub-record failed
+            line["two_level"] = {"error": f"{type(e).__name__}: {e}"}
+            failed = True
+
     if (world > 1 or args.force_sharded) and not args.no_sharded:
         # The headline figure stands on its own: whatever happens to the sharded record -- an exception, or a rank that died and
-        # left the others waiting inside a collective -- rank 0 still prints its line (with the failure in it) and every rank leaves.
+        # left the others waiting inside a collective -- rank 0 still prints its line, with the failure in it AND in the exit
+        # status: a run whose multi-GPU path hung or raised must not read as green.
         def give_up():
             if rank == 0:
                 line["sharded"] = {"error": "no result after %d s (a rank failed inside a collective?)" % args.sharded_timeout}
+                line["sharded_error"] = line["sharded"]["error"]
                 emit(line)
-            os._exit(0)
+            os._exit(3)
 
         watchdog = threading.Timer(args.sharded_timeout, give_up)
         watchdog.daemon = True
@@ -537,13 +578,30 @@ def main() -> int:
         except Exception as e:
             rec = {"error": f"{type(e).__name__}: {e}"}
         watchdog.cancel()
+        if rec is not None and "error" in rec:
+            failed = True
         if rank == 0:
             line["sharded"] = rec
+            # the figures a reader of a SCALE record wants, at the top level: the headline `value` is replicas of configs[1] and
+            # scales whatever the sharded loop does
+            if rec is not None and "error" not in rec:
+                line["sharded_mrays"] = rec["value"]
+                line["sharded_ms_per_step"] = rec["ms_per_step"]
+                line["sharded_ranks_seen"] = rec["ranks_seen"]
+                line["sharded_records_routed_fraction"] = rec["records_routed_fraction"]
+                if rec["ranks_seen"] != world:
+                    line["sharded_error"] = "%d of %d ranks took part" % (rec["ranks_seen"], world)
+                    failed = True
+            else:
+                line["sharded_error"] = (rec or {}).get("error", "no record")
+                failed = True
     if rank == 0:
         emit(line)
     if world > 1:
+        if failed:
+            os._exit(3)  # (ranks that did not fail may be waiting in a collective for one that did: leave without the group's goodbye)
         dist.destroy_process_group()
-    return 0
+    return 3 if failed else 0
 
 
 if __name__ == "__main__":

@@ -44,3 +44,11 @@ def test_one_gpu_default_starts_no_children():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry"], env=_clean_env(), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert _json_line(p.stdout)["n_gpus"] == 1
+
+
+def test_a_failing_rank_fails_the_run():
+    """A rank that gives up (a sharded record that errored or hung: bench.py exits 3 there) must not read as a green run."""
+    env = dict(_clean_env(), PANDORA_BENCH_DRY_FAIL_RANK="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert _json_line(p.stdout)["n_gpus"] == 2  # the line still went out

@@ -45,5 +45,17 @@ def test_landscape_config_small(frac):
 
 @pytest.mark.timeout(450)
 def test_single_level_shadow_rays_small():
-    j = _bench("--tris", "20000", "--side", "512", "--rays", "shadow", "--kind", "any")
-    assert j["cpu_baseline"]["gpu_matches_bit_exact"] is True and 0.05 < j["config"]["hit_fraction"] < 0.95
+    j = _bench("--tris", "20000", "--side", "512", "--rays", "shadow", "--kind", "any", "--no-two-level")
+    assert j["cpu_baseline"]["gpu_matches_bit_exact"] is True and 0.05 < j["config"]["hit_fraction"] < 0.95 and "two_level" not in j
+
+
+@pytest.mark.timeout(450)
+def test_default_line_carries_the_two_level_record_small():
+    """the driver's command (`bench.py --gpus 1`) at toy sizes: headline = configs[1], `two_level` = configs[2] with its own
+    roofline, CPU baseline and bit-exact verdict"""
+    j = _bench("--tris", "20000", "--side", "512", "--city-blocks", "4", "--svdag", "32", "--two-level-steps", "2")
+    assert j["cpu_baseline"]["gpu_matches_bit_exact"] is True and "configs[1]" in j["config"]["workload"]
+    t = j["two_level"]
+    assert "error" not in t and t["gpu_matches_bit_exact"] is True and t["value"] > 0 and t["ms_per_step"] > 0
+    assert "configs[2]" in t["config"]["workload"] and t["roofline"]["frac"] > 0 and t["cpu_baseline"]["value"] > 0
+    assert "sharded" not in j
