@@ -175,7 +175,7 @@ def run_single(args, pa, torch, ctx, dev, rank):
         cpu = None
         if not args.no_cpu:
             import oracle_binding as ob
-            threads = max(1, min(16, os.cpu_count() or 1))
+            threads = pa.accel.host_threads()
             sample = min(n, args.cpu_sample or n)
             orc = ob.OracleBvh8.from_host(hb, mesh)
             sub = np.ascontiguousarray(rays[:, :sample])
@@ -262,7 +262,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
         cpu = None
         if not args.no_cpu:
             import oracle_binding as ob
-            threads = max(1, min(16, os.cpu_count() or 1))
+            threads = pa.accel.host_threads()
             sample = min(n, args.cpu_sample or (1 << 21))
             sub = np.ascontiguousarray(rays[:, :sample])
             import dataclasses
@@ -348,7 +348,7 @@ def run_landscape(args, pa, torch, ctx, dev, rank):
         cpu = None
         if not args.no_cpu:
             import oracle_binding as ob
-            threads = max(1, min(16, os.cpu_count() or 1))
+            threads = pa.accel.host_threads()
             sample = min(n, args.cpu_sample or (1 << 20))
             sub = np.ascontiguousarray(rays[:, :sample])
             scene = ob.scene_from_instanced(tl)
@@ -516,6 +516,8 @@ def main() -> int:
         torch.cuda.synchronize()
         return time.perf_counter() - t0, float(np.mean(kernel_ms))
 
+    if world > 1:
+        args.no_cpu = True  # (contract: the CPU baseline is timed on rank 0 at N = 1 only; the other ranks would wait for it)
     ctx = pa.accel.Context(dev.index)
     step, n, finish = {"single": run_single, "two-level": run_two_level, "landscape": run_landscape}[args.config](args, pa, torch, ctx, dev, rank)
     elapsed, k_ms = timed(ctx, step, args.steps, args.warmup)

@@ -19,6 +19,17 @@ from . import capi
 from .capi import PandoraError
 
 
+def host_threads(cap: int = 16) -> int:
+    """Host worker threads this process may use: PANDORA_HOST_THREADS when set, else the node's CPUs divided by the ranks sharing it
+    (LOCAL_WORLD_SIZE under torch.distributed.run / bench.py's own launcher), at most `cap`. Eight ranks building their scenes on
+    16 threads each would oversubscribe the host they share."""
+    env = os.environ.get("PANDORA_HOST_THREADS")
+    if env:
+        return max(1, int(env))
+    local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(cap, (os.cpu_count() or 1) // local))
+
+
 def _check(rc: int, ctx=None, what: str = ""):
     if rc != capi.OK:
         msg = capi.lib().pgpu_last_error(ctx).decode() if ctx else what
@@ -771,7 +782,7 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     starts = np.concatenate([[0], np.cumsum(counts)])
     groups = [np.ascontiguousarray(order[starts[g]:starts[g + 1]]) for g in range(ng)]
     # the per-group builds are independent C calls (ctypes releases the GIL): run them on a few threads
-    workers = max(1, min(16, os.cpu_count() or 1, len(groups)))
+    workers = max(1, min(host_threads(), len(groups)))
     want = np.ones(ng, bool) if build_group is None else np.asarray(build_group(counts), bool)
     build = lambda gi: build_bvh8(pos, idx, groups[gi], max_leaf) if want[gi] else None
     if workers > 1:
@@ -930,7 +941,7 @@ def build_instanced_two_level(pos, idx, protos, inst_proto, inst_matrix, prims_p
         alone = np.concatenate([np.zeros(tris.size, np.uint8), np.ones(insts.size, np.uint8)])
         return tris, insts, build_bvh8_boxes(boxes, alone), np.concatenate([boxes[:, :3].min(axis=0), boxes[:, 3:].max(axis=0)])
 
-    workers = max(1, min(16, os.cpu_count() or 1, ng))
+    workers = max(1, min(host_threads(), ng))
     if workers > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(workers) as pool:

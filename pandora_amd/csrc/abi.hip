@@ -1,5 +1,8 @@
 // C-ABI implementation: device context, scene upload, batch tracing. See include/pandora_hip.h.
 #include "context.h"
+#include "trace_ranges.h"
+#include <dlfcn.h>
+#include <cstdlib>
 #include <mutex>
 #include <algorithm>
 #include <cmath>
@@ -10,6 +13,32 @@
 using namespace pandora_hip;
 
 namespace pandora_hip {
+
+const RoctxApi& roctxApi()
+{
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        const char* env = std::getenv("PANDORA_ROCTX");
+        if (env && env[0] == '0')
+            return a;
+        // rocprofv3's roctx (ROCm 7), then the roctracer one; an already loaded copy (the profiler preloads its own) is found first
+        for (const char* name : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
+            void* lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (!lib)
+                lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (!lib)
+                continue;
+            a.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+            a.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+            if (a.push && a.pop)
+                return a;
+            a.push = nullptr;
+            a.pop = nullptr;
+        }
+        return a;
+    }();
+    return api;
+}
 
 int fail(pgpu_ctx* c, int code, const char* what, hipError_t e)
 {
@@ -251,7 +280,7 @@ int pgpu_init(int device_id, pgpu_ctx** out)
     if (e == hipSuccess)
         e = hipGetDeviceProperties(&prop, device_id);
     if (e != hipSuccess) {
-        delete c;
+        pgpu_shutdown(c); // (releases whatever the steps above did create)
         return PGPU_ERR_HIP;
     }
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -268,7 +297,8 @@ void pgpu_shutdown(pgpu_ctx* c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
     destroyComm(c);
     for (void* p : c->owned)
         (void)hipFree(p);
@@ -305,9 +335,12 @@ void pgpu_shutdown(pgpu_ctx* c)
     for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv })
         if (b->ptr)
             (void)hipFree(b->ptr);
-    (void)hipEventDestroy(c->ev0);
-    (void)hipEventDestroy(c->ev1);
-    (void)hipStreamDestroy(c->stream);
+    if (c->ev0)
+        (void)hipEventDestroy(c->ev0);
+    if (c->ev1)
+        (void)hipEventDestroy(c->ev1);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -377,6 +410,7 @@ int pgpu_get_counters(pgpu_ctx* c, pgpu_counters* out)
 int pgpu_upload_mesh(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
     uint32_t* mesh_id)
 {
+    const TraceRange range_("pgpu_upload_mesh");
     if (!c || !positions || !indices || !mesh_id || n_vertices == 0 || n_triangles == 0)
         return fail(c, PGPU_ERR_INVALID, "pgpu_upload_mesh: null or empty argument");
     for (size_t i = 0; i < 3 * n_triangles; ++i)
@@ -507,6 +541,7 @@ int pgpu_upload_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const ui
 int pgpu_upload_bvh8_instanced(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, uint32_t* bvh_id)
 {
+    const TraceRange range_("pgpu_upload_bvh8");
     if (!c || !bvh_id || (n_instances && !instances))
         return fail(c, PGPU_ERR_INVALID, "pgpu_upload_bvh8: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -558,6 +593,7 @@ int pgpu_stage_bvh8(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uin
 int pgpu_stage_bvh8_instanced(pgpu_ctx* c, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, const pgpu_instance* instances, size_t n_instances, uint32_t* bvh_id)
 {
+    const TraceRange range_("pgpu_stage_bvh8");
     if (!c || !bvh_id || (n_instances && !instances))
         return fail(c, PGPU_ERR_INVALID, "pgpu_stage_bvh8: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -625,6 +661,7 @@ int pgpu_set_leaf_copy(pgpu_ctx* c, int mode)
 int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
     const pgpu_hits* hits, uint32_t* any_hit, void* stream_)
 {
+    const TraceRange range_("pgpu_trace_bvh8");
     if (!c || !rays)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_bvh8: null argument");
     if (bvh_id >= c->bvhs.size())
@@ -721,6 +758,7 @@ int pgpu_trace_bvh8(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode, const 
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     HIP_TRY(c, launchBvh8Trace(a, kind, tri_mode, c->stats, blocks, stream));
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    c->timingStale = false;
 
     if (mem == PGPU_MEM_HOST) {
         if (kind == PGPU_CLOSEST) {
@@ -754,7 +792,7 @@ int pgpu_sync(pgpu_ctx* c, void* stream_)
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
     HIP_TRY(c, hipStreamSynchronize(stream));
-    if (hipEventQuery(c->ev1) == hipSuccess)
+    if (!c->timingStale && hipEventQuery(c->ev1) == hipSuccess)
         (void)hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1);
     if (c->topCountersDirty) {
         // SVDAG counters of the pgpu_top_episode calls since the last sync (g_stats.svdag.*): they accumulate

@@ -37,6 +37,7 @@ struct pgpu_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     float lastKernelMs = 0.0f;
+    bool timingStale = false; // the last entry point recorded no timing events (stream capture): ev0 / ev1 belong to an earlier call
     bool stats = false;
     int blocksPerCU = 0; // 0 = as many as LDS / registers allow
     uint32_t chunk = 0; // work items a wave draws at a time, 0 = automatic

@@ -132,9 +132,20 @@ int pgpu_trace_bvh8_noalloc(pgpu_ctx* c, uint32_t bvh_id, int kind, int tri_mode
         HIP_TRY(c, hipMemsetAsync(a.inst_out, 0xFF, n * 4, stream));
     if (c->stats)
         HIP_TRY(c, hipMemsetAsync(c->statsDev, 0, 64, stream));
-    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    // Timing events only outside stream capture: an event recorded into a graph cannot be timed, and pgpu_last_kernel_ms would
+    // keep a stale figure -- under capture it reads 0 (no timing available there).
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess)
+        capturing = hipStreamCaptureStatusNone;
+    const bool timed = capturing == hipStreamCaptureStatusNone;
+    if (timed)
+        HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    else
+        c->lastKernelMs = 0.0f;
+    c->timingStale = !timed; // (pgpu_sync must not refresh the figure from events an earlier call recorded)
     HIP_TRY(c, launchBvh8Trace(a, kind, tri_mode, c->stats, blocks, stream));
-    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    if (timed)
+        HIP_TRY(c, hipEventRecord(c->ev1, stream));
     return PGPU_OK;
 }
 }

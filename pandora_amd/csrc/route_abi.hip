@@ -168,6 +168,7 @@ int pgpu_trace_leaf_records(pgpu_ctx* c, int kind, int tri_mode, const float* re
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     const int rc = traceLeafRecords(c, kind, tri_mode, records, k, results, stream);
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    c->timingStale = false;
     return rc;
 }
 

@@ -596,6 +596,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         flip ^= 1;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    c->timingStale = false;
     unsigned long long cnt[2] = { 0, 0 };
     HIP_TRY(c, hipMemcpyAsync(cnt, c->topCounters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));

@@ -3,6 +3,7 @@
 // that replaces the reference's TaskGraph flush loop (task_graph.cpp:19-56) around
 // OfflineBatchingAccelerationStructure (offline_batching_acceleration_structure.h:158-260,406-437).
 #include "context.h"
+#include "trace_ranges.h"
 #include <limits>
 #include <cmath>
 #include <algorithm>
@@ -156,6 +157,7 @@ int commitLeafGroup(pgpu_ctx* c, const LeafGroupPlan& plan, hipStream_t stream)
 {
     if (plan.arrived.empty() && plan.evicted.empty())
         return PGPU_OK;
+    const TraceRange range_("leaf streaming: copy group"); // the reference's static-data load (task_graph.h:249-259, offline_batching...h:165-175)
     for (int ev : plan.waitLaunches)
         HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->launchEvents[size_t(ev)], 0));
     const size_t nSeg = c->leafCopyMode == 0 ? plan.arrived.size() : 0, nFix = plan.arrived.size() + plan.evicted.size();
@@ -235,6 +237,16 @@ static int rebuildLeafDags(pgpu_ctx* c)
     const int rc = uploadOwned(c, ld.data(), ld.size(), &dl);
     if (rc != PGPU_OK)
         return rc;
+    // the previous table (every policy change and every upload builds a new one) is released once nothing queued can read it
+    if (c->top.leafDags) {
+        void* const old = const_cast<LeafDagDev*>(c->top.leafDags);
+        HIP_TRY(c, hipDeviceSynchronize());
+        auto it = std::find(c->owned.begin(), c->owned.end(), old);
+        if (it != c->owned.end()) {
+            c->owned.erase(it);
+            HIP_TRY(c, hipFree(old));
+        }
+    }
     c->top.leafDags = dl;
     return PGPU_OK;
 }
@@ -274,6 +286,7 @@ int pgpu_set_svdag_defer(pgpu_ctx* c, uint32_t min_rays, uint32_t passes)
 
 int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags)
 {
+    const TraceRange range_("pgpu_upload_svdags");
     if (!c || !words || !dags || n_words == 0 || n_dags == 0)
         return fail(c, PGPU_ERR_INVALID, "pgpu_upload_svdags: null or empty argument");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -400,6 +413,7 @@ int pgpu_upload_svdags(pgpu_ctx* c, const uint32_t* words, size_t n_words, const
 
 int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint32_t root, const pgpu_leaf* leaves, size_t n_leaves)
 {
+    const TraceRange range_("pgpu_upload_top_bvh4");
     if (!c || !nodes112 || !leaves || n_nodes == 0 || n_leaves == 0 || root >= n_nodes)
         return fail(c, PGPU_ERR_INVALID, "pgpu_upload_top_bvh4: null or empty argument");
     if (n_leaves < 2)
@@ -448,6 +462,7 @@ int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint
 int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
     const pgpu_hits* hits, uint32_t* any_hit, pgpu_counters* counters, void* stream_)
 {
+    const TraceRange range_("pgpu_trace");
     if (!c || !rays)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace: null argument");
     if (!c->haveTop)
@@ -714,7 +729,10 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ta.may_park = r < nl ? 1u : 0u; // a ray pauses at most once per batching point
             ta.only_culled = 0u;
             const uint32_t listBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (bound + 255u) / 256u));
-            HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (bound + 255u) / 256u)), stream));
+            {
+                const TraceRange r_("round: top-level episode");
+                HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (bound + 255u) / 256u)), stream));
+            }
             HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), countOut, stream, dLeafCount, c->cursor, &c->roundCounts[r]));
             // The parked rays by batching point, for the bottom level (binning). The next top-level episode takes the same list when
             // its waves run in lockstep -- rays of one batching point walk the same nodes and cast through the same DAG -- and the
@@ -738,9 +756,13 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             rc = planBvh8Launch(c, deepest, bound, ba, &blocks);
             if (rc != PGPU_OK)
                 return rc;
-            HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+            {
+                const TraceRange r_("round: bottom level (per-point BVH8)"); // the reference's leaf task kernel (task_graph.h:259)
+                HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+            }
             active = nextActive;
             if (r >= 1) {
+                const TraceRange w_("round: wait for the previous round's parked count");
                 HIP_TRY(c, hipEventSynchronize(c->roundEv[(r - 1) & 1u]));
                 const uint32_t parked = c->roundCounts[r - 1];
                 if (parked == 0)
@@ -792,7 +814,10 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             }
             ta.only_culled = 1u;
         }
-        HIP_TRY(c, launchTopTraverse(ta, kind, topBlocks, stream));
+        {
+            const TraceRange r_("round: top-level episode");
+            HIP_TRY(c, launchTopTraverse(ta, kind, topBlocks, stream));
+        }
         } // nActive > 0
         if (nHeld > 0) // the rays still waiting from earlier rounds are part of this round's queues
             HIP_TRY(c, launchAddCounts(dLeafCount, dHeldCount, uint32_t(nl), stream));
@@ -944,7 +969,10 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 rc = planBvh8Launch(c, deepest, hi - lo, ba, &blocks);
                 if (rc != PGPU_OK)
                     return rc;
-                HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+                {
+                    const TraceRange r_("round: bottom level, one group of cached batching points");
+                    HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+                }
                 if (!plan.touched.empty()) {
                     const size_t ev = c->launchEventNext++ % c->launchEvents.size();
                     HIP_TRY(c, hipEventRecord(c->launchEvents[ev], stream));
@@ -968,6 +996,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
         nHeld = nextHeld;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    c->timingStale = false;
 
     if (mem == PGPU_MEM_HOST) {
         if (kind == PGPU_CLOSEST) {
@@ -1026,6 +1055,7 @@ int pgpu_ray_state_init(pgpu_ctx* c, size_t n, const float* tfar, uint32_t* node
 int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_t* active, size_t n_active, uint32_t* node, uint64_t* stack,
     const float* t_state, uint32_t* visits, uint32_t* any_hit, uint32_t* parked_leaf, int may_park, void* stream_)
 {
+    const TraceRange range_("pgpu_top_episode");
     if (!c || !rays || !node || !stack || !parked_leaf)
         return fail(c, PGPU_ERR_INVALID, "pgpu_top_episode: null argument");
     if (!c->haveTop)
@@ -1076,6 +1106,7 @@ int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_
 int pgpu_trace_leaves(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, const uint32_t* work_ray, const uint32_t* work_leaf,
     size_t n_work, const pgpu_hits* hits, uint32_t* any_hit, void* stream_)
 {
+    const TraceRange range_("pgpu_trace_leaves");
     if (!c || !rays || !work_ray || !work_leaf)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_leaves: null argument");
     if (!c->haveTop)
@@ -1149,6 +1180,7 @@ int pgpu_trace_leaves(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
     HIP_TRY(c, hipEventRecord(c->ev0, stream));
     HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    c->timingStale = false;
     return PGPU_OK;
 }
 }

@@ -18,11 +18,26 @@
 #include <cfloat>
 #include <condition_variable>
 #include <mutex>
+#include <cstdlib>
 #include <thread>
 #include <cmath>
 #include <cstring>
 #include <numeric>
 #include <vector>
+
+// Host worker threads this process may use: PANDORA_HOST_THREADS when set, else the node's CPUs divided by the ranks that share it
+// (LOCAL_WORLD_SIZE, set by torch.distributed.run and bench.py's launcher), at most 16.
+static unsigned hostThreads()
+{
+    if (const char* e = std::getenv("PANDORA_HOST_THREADS"))
+        if (const long v = std::strtol(e, nullptr, 10); v > 0)
+            return unsigned(std::min<long>(v, 256));
+    long local = 1;
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE"))
+        local = std::max<long>(1, std::strtol(e, nullptr, 10));
+    const long hw = long(std::thread::hardware_concurrency());
+    return unsigned(std::max<long>(1, std::min<long>(16, hw / local)));
+}
 
 namespace {
 
@@ -525,7 +540,7 @@ int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32
 {
     if (!positions || !indices || !group_of_prim || !n_groups || max_prims == 0)
         return PGPU_ERR_INVALID;
-    const unsigned nThreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned nThreads = hostThreads();
     auto parallelFor = [&](size_t n, auto&& body) { // body(begin, end) on contiguous slices
         const size_t slices = n < (size_t(1) << 16) ? 1 : nThreads;
         std::vector<std::thread> pool;

@@ -29,7 +29,9 @@ def test_no_alloc_entry_point_matches_trace_bvh8():
     dev = torch.device("cuda", 0)
     mesh = pa.scenes.g_atrium(20000)
     hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
-    assert 7 * hb.depth + 8 > 11, "the tree must be deep enough for stack entries to leave the LDS window"
+    # the LDS stack window holds 12 entries (kernels.h stackWindow); a tree of depth d needs up to 7 d + 8: more than 12 means
+    # entries really leave the window and the static spill area is in use
+    assert 7 * hb.depth + 8 > 12, "the tree must be deep enough for stack entries to leave the LDS window"
     prim = pa.scenes.primary_rays((3, 3, 9), (28, 5, 9), (0, 1, 0), 70, 192, 192)
     rnd = pa.scenes.random_rays((0, 0, 0), (30, 12, 18), 30000, seed=5)
     big = np.ascontiguousarray(np.concatenate([prim, rnd], axis=1))
