@@ -23,6 +23,7 @@
 // Float semantics: contraction off; min/max written as compare+select so that NaN behaves like
 // x86 minps/maxps (second operand wins), see SURVEY.md F10.
 #include "kernels.h"
+#include "wave_ops.h"
 #include <hip/hip_runtime.h>
 
 #pragma clang fp contract(off)
@@ -164,8 +165,6 @@ __device__ __forceinline__ TriHit triWatertight(float ox, float oy, float oz, fl
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kRaysPerWave = 16;
 constexpr uint32_t kStagePerWave = kRaysPerWave * 256u; // one 256-byte node per ray
-constexpr uint64_t kQuadLane0 = 0x1111111111111111ull;
-constexpr uint64_t kQuadLane3 = 0x8888888888888888ull;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -175,33 +174,6 @@ template <typename T>
 __device__ __forceinline__ T& at32(T* base, uint32_t byteOffset)
 {
     return *reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + byteOffset);
-}
-
-// value of lane `(lane & ~3) | perm[lane & 3]` (v_*_dpp quad_perm: folded into the consuming VALU instruction)
-template <int P0, int P1, int P2, int P3>
-__device__ __forceinline__ int quadPerm(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);
-}
-template <int K>
-__device__ __forceinline__ float quadBcast(float v) { return __int_as_float(quadPerm<K, K, K, K>(__float_as_int(v))); }
-__device__ __forceinline__ uint32_t quadOr(uint32_t v)
-{
-    v |= uint32_t(quadPerm<1, 0, 3, 2>(int(v)));
-    v |= uint32_t(quadPerm<2, 3, 0, 1>(int(v)));
-    return v;
-}
-__device__ __forceinline__ uint32_t quadAdd(uint32_t v)
-{
-    v += uint32_t(quadPerm<1, 0, 3, 2>(int(v)));
-    v += uint32_t(quadPerm<2, 3, 0, 1>(int(v)));
-    return v;
-}
-__device__ __forceinline__ float quadMin(float v)
-{
-    v = fminf(v, __int_as_float(quadPerm<1, 0, 3, 2>(__float_as_int(v))));
-    v = fminf(v, __int_as_float(quadPerm<2, 3, 0, 1>(__float_as_int(v))));
-    return v;
 }
 
 // The LDS side of a global_load_lds is M0 + immediate offset + lane * 16 (measured: tools/dma_probe.hip): the

@@ -3,6 +3,7 @@
 // and merging the results. A record is 9 dwords: ox oy oz dx dy dz tnear tfar leaf (tfar = the ray's current t for
 // closest hit); a result is {t, obj, u, v} (closest) or {hit} (any).
 #include "kernels.h"
+#include "wave_ops.h"
 #include <hip/hip_runtime.h>
 
 namespace pandora_hip {
@@ -10,31 +11,6 @@ namespace pandora_hip {
 namespace {
 
 constexpr uint32_t kMaxRanks = 64;
-
-struct KeyGroup {
-    uint32_t leader, rank, size;
-};
-// lanes with equal keys elect a leader; every lane learns leader, its rank inside the group and the group size
-__device__ __forceinline__ KeyGroup groupByKey(uint32_t key, bool active)
-{
-    KeyGroup kg;
-    kg.leader = threadIdx.x & 63u;
-    kg.rank = 0;
-    kg.size = 1;
-    uint64_t todo = __ballot(active);
-    while (todo != 0) {
-        const int l = __builtin_ctzll(todo);
-        const uint32_t k = uint32_t(__builtin_amdgcn_readlane(int(key), l));
-        const uint64_t same = __ballot(active && key == k);
-        if (active && key == k) {
-            kg.leader = uint32_t(l);
-            kg.rank = __builtin_amdgcn_mbcnt_hi(uint32_t(same >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(same), 0u));
-            kg.size = uint32_t(__popcll(same));
-        }
-        todo &= ~same;
-    }
-    return kg;
-}
 
 __device__ __forceinline__ uint32_t destOf(const uint32_t* __restrict__ parkedLeaf, const uint32_t* __restrict__ owner, uint32_t nLeaves, uint32_t i,
     uint32_t n, uint32_t* leaf)

@@ -619,6 +619,9 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ta.counters = dCounters;
     ta.lanes_refill_min = c->topVariant == 2 ? c->topRefillMin : 0u;
     ta.lanes_cast_trips = c->topCastTrips;
+    // the next episode's list: the binning's (rays of one batching point adjacent: coherent waves) or the parked rays in ray-id order
+    // (coalesced reads; a kernel whose lanes are independent has no coherence to lose)
+    const bool listById = c->topVariant == 2;
 
     Bvh8TraceArgs ba {};
     ba.bvhs = c->bvhTable;
@@ -742,7 +745,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             HIP_TRY(c, launchBinByLeaf(active, dParkedLeaf, bound, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh, dWorkLeaf,
                            listBlocks, stream, false, countIn));
             uint32_t* nextActive = workRayOut;
-            if (ta.lanes_refill_min != 0u) {
+            if (listById) {
                 nextActive = dIds[r & 1u];
                 HIP_TRY(c, launchCompactParked(active, dParkedLeaf, bound, countIn, uint32_t(nl), dSliceCount, dSliceStart, dSliceFill, dParkedCount + 8,
                                nextActive, std::max(1u, std::min(4096u, (bound + 1023u) / 1024u)), stream));

@@ -16,6 +16,7 @@
 // The SVDAG cast drops the fourth SIMD lane of the reference (the (x,y,z,1) padding lane whose
 // 0x07FFFFFF mask only burns iterations); the oracle proves the boolean is unchanged.
 #include "kernels.h"
+#include "wave_ops.h"
 #include <hip/hip_runtime.h>
 
 #pragma clang fp contract(off)
@@ -225,33 +226,6 @@ __device__ __forceinline__ uint32_t slabs4(const float* nf, float ox, float oy, 
         hitMask |= uint32_t(tmin[i] <= tmax) << i;
     }
     return hitMask;
-}
-
-// Many rays of a wave usually want the same counter (coherent rays park at the same batching point), and
-// same-address atomics from single lanes serialise in L2. Lanes with equal keys therefore elect a leader that adds
-// the group's size once; every lane learns its leader, its rank inside the group and the group size.
-struct KeyGroup {
-    uint32_t leader, rank, size;
-};
-__device__ __forceinline__ KeyGroup groupByKey(uint32_t key, bool active)
-{
-    KeyGroup kg;
-    kg.leader = threadIdx.x & 63u;
-    kg.rank = 0;
-    kg.size = 1;
-    uint64_t todo = __ballot(active);
-    while (todo != 0) {
-        const int l = __builtin_ctzll(todo);
-        const uint32_t k = uint32_t(__builtin_amdgcn_readlane(int(key), l));
-        const uint64_t same = __ballot(active && key == k);
-        if (active && key == k) {
-            kg.leader = uint32_t(l);
-            kg.rank = __builtin_amdgcn_mbcnt_hi(uint32_t(same >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(same), 0u));
-            kg.size = uint32_t(__popcll(same));
-        }
-        todo &= ~same;
-    }
-    return kg;
 }
 
 // the ray of an episode: from its 32-byte record when the trace keeps them (TopTraceArgs::ray_aos), else from the eight arrays
