@@ -465,8 +465,9 @@ int pgpu_set_ray_layout(pgpu_ctx*, int lanes_per_ray);
 int pgpu_set_round_lookahead(pgpu_ctx*, int on);
 /* The top-level kernel of pgpu_trace: 1 = waves in lockstep (64 rays start an episode together and the wave waits for the
  * slowest), 2 = lanes take the next ray as soon as theirs has parked or left, and a wave runs BVH4 steps and SVDAG cast trips
- * as separate phases, 0 = automatic. refill_min = idle lanes of a wave before it fetches new rays, cast_trips = cast trips
- * per cast phase (0 = defaults; variant 2 only). Results do not depend on any of them. */
+ * as separate phases, 3 = lockstep waves for a trace's first episode (every ray from the root) and variant 2 for the resumed rays
+ * of the later rounds, 0 = automatic. refill_min = idle lanes of a wave before it fetches new rays, cast_trips = cast trips
+ * per cast phase (0 = defaults; variants 2 and 3). Results do not depend on any of them. */
 int pgpu_set_top_variant(pgpu_ctx*, int variant, int refill_min, int cast_trips);
 
 #ifdef __cplusplus

@@ -255,7 +255,7 @@ extern "C" {
 
 int pgpu_set_top_variant(pgpu_ctx* c, int variant, int refill_min, int cast_trips)
 {
-    if (!c || variant < 0 || variant > 2 || refill_min < 0 || refill_min > 64 || cast_trips < 0 || cast_trips > 64)
+    if (!c || variant < 0 || variant > 3 || refill_min < 0 || refill_min > 64 || cast_trips < 0 || cast_trips > 64)
         return PGPU_ERR_INVALID;
     c->topVariant = variant;
     c->topRefillMin = refill_min ? uint32_t(refill_min) : 16u;
@@ -617,11 +617,11 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     ta.leaf_count = dLeafCount;
     ta.step_cap = uint32_t(std::min<uint64_t>(0xFFFFFFF0ull, 8ull * (uint64_t(c->top.n_nodes) + c->top.n_leaves) + 64ull));
     ta.counters = dCounters;
-    ta.lanes_refill_min = c->topVariant == 2 ? c->topRefillMin : 0u;
+    ta.lanes_refill_min = c->topVariant == 2 ? c->topRefillMin : 0u; // (variant 3: set per round below)
     ta.lanes_cast_trips = c->topCastTrips;
     // the next episode's list: the binning's (rays of one batching point adjacent: coherent waves) or the parked rays in ray-id order
     // (coalesced reads; a kernel whose lanes are independent has no coherence to lose)
-    const bool listById = c->topVariant == 2;
+    const bool listById = c->topVariant == 2 || c->topVariant == 3;
 
     Bvh8TraceArgs ba {};
     ba.bvhs = c->bvhTable;
@@ -731,6 +731,8 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ba.ray_aos = dRayAos;
             ta.may_park = r < nl ? 1u : 0u; // a ray pauses at most once per batching point
             ta.only_culled = 0u;
+            if (c->topVariant == 3) // lockstep waves for the first episode (every ray from the root, coalesced reads), independent lanes for the resumed rays
+                ta.lanes_refill_min = r ? c->topRefillMin : 0u;
             const uint32_t listBlocks = std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (bound + 255u) / 256u));
             {
                 const TraceRange r_("round: top-level episode");

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
 // ray is the same in both kernels, so are the results.
 // ---------------------------------------------------------------------------------------------------
 template <bool ANY, bool NODES_IN_LDS>
-__global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs a)
+__global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void topTraverseLanesKernel(TopTraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char topLds[];
     uint32_t* const dagStack = reinterpret_cast<uint32_t*>(topLds);
@@ -468,11 +468,16 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs
     uint32_t chunk = uint32_t(__builtin_amdgcn_readfirstlane(int(blockIdx.x * (kTopBlock / 64u) + (threadIdx.x >> 6))));
     uint32_t chunkNext = chunk * 64u, chunkEnd = min(chunkNext + 64u, nActive);
 
-    int mode = 0; // 0 idle, 1 walking the BVH4, 2 inside an SVDAG cast
+    int mode = 0; // 0 idle, 1 walking the BVH4, 2 inside an SVDAG cast, 3 back from a cast that missed: the ray is reloaded, then 1
     uint32_t w = 0, ray = 0, node = 0, steps = 0, castLeaf = 0;
     uint64_t stack = 0;
-    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0, tnear = 0, tfar = 0;
+    // A lane is walking or casting, never both: the ray (origin, 1 / direction, interval) and the cast's per-axis state share
+    // their registers -- the cast overwrites the ray and a lane whose cast missed reloads it (one 32-byte record + the far end)
+    // before it walks on. Held side by side they cost 84 VGPRs = 5 waves per SIMD; shared, 64 = 8 waves, and this kernel lives
+    // on occupancy.
     CastState cs {};
+    float &ox = cs.tCoef[0], &oy = cs.tCoef[1], &oz = cs.tCoef[2], &ix = cs.tBias[0], &iy = cs.tBias[1], &iz = cs.tBias[2];
+    float &tnear = cs.pos[0], &tfar = cs.pos[1];
 
     for (;;) {
         // ---------------------------------------------------------------- idle lanes take new rays
@@ -498,17 +503,22 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs
                 if (ANY && a.any_out[ray] != 0u) {
                     a.parked_leaf[w] = PGPU_MISS_ID; // a shadow ray already occluded in its last leaf is done (offline_batching...h:246-247)
                 } else {
-                    float dx, dy, dz;
-                    loadRay(a, ray, ox, oy, oz, dx, dy, dz, tnear);
-                    tfar = ANY ? a.tfar_in[ray] : a.tfar_state[ray]; // simdRay is rebuilt from the ray at every resume (:243-254)
-                    ix = 1.0f / dx; // :241
-                    iy = 1.0f / dy;
-                    iz = 1.0f / dz;
                     node = a.node[ray];
                     stack = a.stack[ray];
                     steps = 0;
-                    mode = 1;
+                    mode = 3;
                 }
+            }
+        }
+        if (__ballot(mode == 3) != 0) {
+            if (mode == 3) {
+                float dx, dy, dz;
+                loadRay(a, ray, ox, oy, oz, dx, dy, dz, tnear);
+                tfar = ANY ? a.tfar_in[ray] : a.tfar_state[ray]; // simdRay is rebuilt from the ray at every resume (:243-254)
+                ix = 1.0f / dx; // :241
+                iy = 1.0f / dy;
+                iz = 1.0f / dz;
+                mode = 1;
             }
         }
 
@@ -564,6 +574,7 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs
                                         mode = 2;
                                     } else {
                                         ++nCulled; // the ray misses the DAG's cube: the traversal goes on at the same node
+                                        mode = 3;  // (castInit has overwritten the ray)
                                     }
                                 } else {
                                     fin = true;
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(kTopBlock) void topTraverseLanesKernel(TopTraceArgs
                         leafId = castLeaf;
                     } else if (r == 2) {
                         ++nCulled;
-                        mode = 1; // culled: the traversal goes on at the same node
+                        mode = 3; // culled: the traversal goes on at the same node, once the ray is back in its registers
                     }
                 }
                 if (__ballot(mode == 2 && !fin) == 0)

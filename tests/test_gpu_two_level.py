@@ -85,15 +85,16 @@ def test_deferred_svdag_casts_match_oracle(two_level, passes):
         ctx.set_svdag_defer(0)
 
 
+@pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("refill_min,cast_trips", [(0, 0), (1, 1), (64, 8), (7, 3)])
-def test_top_level_lanes_kernel_matches_oracle(two_level, refill_min, cast_trips):
+def test_top_level_lanes_kernel_matches_oracle(two_level, refill_min, cast_trips, variant):
     """pgpu_set_top_variant(2): the top-level kernel whose lanes take the next ray as soon as theirs has parked or left, with
     BVH4 steps and SVDAG cast trips as separate wave phases -- same hits, visit counts and SVDAG counters as the oracle, for
     any refill threshold and phase length, with and without the rounds queued ahead."""
     ctx, mesh, tl, orc = two_level
     ctx.set_ray_layout(0)
     ctx.set_kernel_variant(0, 0, 0)
-    ctx.set_top_variant(2, refill_min, cast_trips)
+    ctx.set_top_variant(variant, refill_min, cast_trips)  # (3: lockstep first episode, independent lanes afterwards)
     ctx.set_round_lookahead(refill_min != 7)
     try:
         for name, rays in _ray_sets(mesh).items():
@@ -116,7 +117,7 @@ def test_top_level_lanes_kernel_matches_oracle(two_level, refill_min, cast_trips
 
 
 @pytest.mark.parametrize("n", [1, 63, 256, 257, 1025])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_tiny_batches_through_the_round_loop(two_level, n, variant):
     """Batches smaller than a block, a wave, a compaction slice: the rounds queued ahead size their launches from the previous
     counts and must neither drop nor repeat a ray."""
