@@ -68,6 +68,10 @@ def parse_args():
     ap.add_argument("--svdag", type=int, default=64, help="two-level / sharded scene: SVDAG resolution (0 = no proxy geometry, svdagRes 0 in the reference)")
     ap.add_argument("--sharded-side", type=int, default=4096, help="N > 1: primary image side per rank of the sharded record (batch ~ side^2 diffuse rays per rank)")
     ap.add_argument("--sharded-blocks", type=int, default=64, help="N > 1: city blocks per side of the sharded record's scene (64 -> 80.8 M triangles, 2048 batching points, ~10 GB of host memory per rank while building; 89 -> 156 M triangles, Moana's unique-triangle count, ~20 GB per rank)")
+    ap.add_argument("--sharded-owners", choices=["lpt", "contiguous"], default="lpt",
+                    help="N > 1: owner rank per batching point -- spread by size over all ranks (every rank gets a sample of the whole scene: balanced ray load, "
+                         "(N-1)/N of the visits travel) or contiguous runs of the top level's leaf order (neighbouring space on one rank: little travels when the "
+                         "rays are at home where they start, tests/test_gpu_sharded.py, but a camera that looks at one region loads one rank)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded record")
     ap.add_argument("--sharded-timeout", type=int, default=420, help="seconds after which the sharded record is given up and the line printed without it")
     ap.add_argument("--force-sharded", action="store_true", help="N = 1: run the sharded record too (one rank owns every batching point; rehearsal of the N > 1 path)")
@@ -382,8 +386,13 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
     from pandora_amd import sharded
     owner_by_group = {}
 
-    def mine(sizes):
-        owner_by_group["o"] = sharded.assign_leaves(sizes, world)  # balanced by triangle count; deterministic on every rank
+    def mine(sizes, top):  # deterministic on every rank
+        if args.sharded_owners == "contiguous":
+            order = np.asarray(top.leaf_order, np.int64)
+            owner_by_group["o"] = np.empty(len(sizes), np.int64)
+            owner_by_group["o"][order] = sharded.assign_leaves_contiguous(np.asarray(sizes)[order], world)
+        else:
+            owner_by_group["o"] = sharded.assign_leaves(sizes, world)  # balanced by triangle count
         return owner_by_group["o"] == rank
 
     t0 = time.perf_counter()
@@ -434,7 +443,7 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
         total_rays, visits, routed, xbytes, ranks, resident, mesh_total = (float(x) for x in sums.tolist())
         el = float(mx.item())
         rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, %d^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (mesh.n_tris, tl.n_leaves, args.svdag, world),
-               "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "svdag_policy": args.svdag_policy, "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
+               "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "owners": args.sharded_owners, "svdag_policy": args.svdag_policy, "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
                "comm_selftest": "ok", "value": total_rays * steps / el / 1e6, "unit": "Mrays/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
                "rays_per_gpu": n, "rounds": cnt["rounds"], "leaf_visits_per_ray": visits / total_rays, "records_routed_per_step": routed,
                "records_routed_fraction": routed / max(1.0, visits), "exchange_bytes_per_step_all_ranks": xbytes,

@@ -31,7 +31,8 @@ enum {
     PGPU_ERR_SINGLE_LEAF = -3, /* top level needs >= 2 batching points (pauseable_bvh4.h:180) */
     PGPU_ERR_DEPTH = -4,       /* tree deeper than the traversal stacks allow */
     PGPU_ERR_NO_SCENE = -5,    /* trace called before the structure it needs was uploaded */
-    PGPU_ERR_NO_DEVICE = -6
+    PGPU_ERR_NO_DEVICE = -6,
+    PGPU_ERR_PEER = -7         /* pgpu_trace_sharded: another rank of the job failed; all ranks left the loop in the same round */
 };
 
 enum { PGPU_CLOSEST = 0, PGPU_ANY = 1 };           /* intersect / intersectAny */
@@ -353,8 +354,15 @@ int pgpu_route_merge(pgpu_ctx*, int kind, const float* results, const uint32_t* 
  * pgpu_set_leaf_owners: owner rank of every batching point (leaf slot order, host array). Needed before pgpu_trace_sharded.
  * pgpu_trace_sharded: collective. Device arrays only (rays, hits, any_hit as in pgpu_trace with PGPU_MEM_DEVICE); n may
  *                      differ between ranks (0 included). One host synchronisation per round (the matrix of record counts).
+ *                      The rays parked at this rank's own batching points are traced on a second stream of the context, next to
+ *                      the record exchange and the trace of the received records; the round's merge waits for both.
  *                      counters additionally reports records_routed (records this rank sent to other ranks) and
  *                      exchange_bytes (bytes this rank sent and received in all-to-alls, both directions).
+ *                      Failures: every buffer a round needs is reserved before the first round (the ranks tell each other their
+ *                      ray counts up front: no round can deliver more records than the other ranks have rays). A rank that fails
+ *                      -- there, or in a launch later -- keeps taking part in its round's collectives and raises a flag that
+ *                      travels with the next count rows; every rank then leaves the loop in that same round, the failing rank
+ *                      with its own error, the others with PGPU_ERR_PEER. Only a failing transport call returns at once.
  * pgpu_film_allreduce: sums the u64 fixed-point films of all ranks in place (the integer all-reduce of SURVEY.md K8). */
 typedef struct {
     void* user;
@@ -373,6 +381,9 @@ int pgpu_set_leaf_owners(pgpu_ctx*, const uint32_t* owner_of_leaf, size_t n_leav
 int pgpu_trace_sharded(pgpu_ctx*, int kind, int tri_mode, const pgpu_rays* rays, size_t n, const pgpu_hits* hits, uint32_t* any_hit,
     pgpu_counters* counters, void* stream);
 int pgpu_film_allreduce(pgpu_ctx*, unsigned long long* film, size_t n_pixels, void* stream);
+/* Test hook: the next pgpu_trace_sharded calls of this rank fail once they have completed `after_rounds` rounds (-1: off), the
+ * way a failed launch would -- to check that every rank leaves the loop together (tests/test_gpu_sharded.py). */
+int pgpu_debug_fail_sharded(pgpu_ctx*, int after_rounds);
 
 /* Film. Sensor::addPixelContribution (graphics_core/sensor.cpp:36-49) over a batch of contributions:
  * `film` holds three u64 per pixel in 40.24 fixed point (sensor.h:29-35), film[3 * pixel[i] + c] += fixed(rgb[i][c]).

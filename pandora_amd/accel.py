@@ -603,6 +603,10 @@ class Context:
             _check(self._L.pgpu_trace_sharded(self._h, kind, tri_mode, C.byref(r), n, C.byref(h), capi.ptr(out["hit"]), C.byref(cnt), stream), self._h)
         return out, {f: int(getattr(cnt, f)) for f, _ in capi.Counters._fields_}
 
+    def debug_fail_sharded(self, after_rounds: int = -1):
+        """Test hook (pgpu_debug_fail_sharded): this rank's trace_sharded fails after that many completed rounds; -1 = off."""
+        _check(self._L.pgpu_debug_fail_sharded(self._h, after_rounds), self._h)
+
     def film_allreduce(self, film, stream: int = 0):
         """Sums the int64 fixed-point films of all ranks in place (pgpu_film_allreduce)."""
         _check(self._L.pgpu_film_allreduce(self._h, capi.ptr(film), int(film.numel() // 3), stream), self._h)
@@ -771,9 +775,10 @@ class TwoLevelScene:
 
 def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4, build_group=None,
                     svdag_device_ctx: "Context | None" = None) -> TwoLevelScene:
-    """build_group: optional callable (group sizes: int array) -> bool array; only those batching points get a bottom-level
-    BVH8 here (the others stay None: they live on another rank). The cut, the top level and the SVDAGs are always whole.
-    svdag_device_ctx: build the SVDAGs on that context's GPU instead of the host."""
+    """build_group: optional callable (group sizes: int array[, top: HostBvh4]) -> bool array; only those batching points get a
+    bottom-level BVH8 here (the others stay None: they live on another rank). A callable that takes two arguments also gets the
+    top level, which is built first (from the groups' bounds) so that ownership can follow its leaf order. The cut, the top
+    level and the SVDAGs are always whole. svdag_device_ctx: build the SVDAGs on that context's GPU instead of the host."""
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
     group_of, ng = partition_prims(pos, idx, prims_per_batching_point)
@@ -781,9 +786,20 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     counts = np.bincount(group_of, minlength=ng)
     starts = np.concatenate([[0], np.cumsum(counts)])
     groups = [np.ascontiguousarray(order[starts[g]:starts[g + 1]]) for g in range(ng)]
+    bounds = np.empty((ng, 6), np.float32)
+    for g, prims in enumerate(groups):
+        v = pos[idx[prims].ravel()]
+        bounds[g, :3] = v.min(axis=0)
+        bounds[g, 3:] = v.max(axis=0)
+    top = build_top_bvh4(bounds)
     # the per-group builds are independent C calls (ctypes releases the GIL): run them on a few threads
     workers = max(1, min(host_threads(), len(groups)))
-    want = np.ones(ng, bool) if build_group is None else np.asarray(build_group(counts), bool)
+    if build_group is None:
+        want = np.ones(ng, bool)
+    else:
+        import inspect
+        two = len(inspect.signature(build_group).parameters) >= 2
+        want = np.asarray(build_group(counts, top) if two else build_group(counts), bool)
     build = lambda gi: build_bvh8(pos, idx, groups[gi], max_leaf) if want[gi] else None
     if workers > 1:
         from concurrent.futures import ThreadPoolExecutor
@@ -791,12 +807,6 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
             bvhs = list(pool.map(build, range(ng)))
     else:
         bvhs = [build(gi) for gi in range(ng)]
-    bounds = np.empty((ng, 6), np.float32)
-    for g, prims in enumerate(groups):
-        v = pos[idx[prims].ravel()]
-        bounds[g, :3] = v.min(axis=0)
-        bounds[g, 3:] = v.max(axis=0)
-    top = build_top_bvh4(bounds)
     dags = build_svdags(pos, idx, groups, svdag_res, device_ctx=svdag_device_ctx) if svdag_res > 0 else None
     return TwoLevelScene(groups, bvhs, top, dags, bounds)
 

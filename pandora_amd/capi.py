@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PANDORA_HIP_LIB") or os.path.join(_HERE, "lib", "libpandora_hip.so")  # (the override is for A/B runs of two builds)
 
-OK, ERR_INVALID, ERR_HIP, ERR_SINGLE_LEAF, ERR_DEPTH, ERR_NO_SCENE, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_INVALID, ERR_HIP, ERR_SINGLE_LEAF, ERR_DEPTH, ERR_NO_SCENE, ERR_NO_DEVICE, ERR_PEER = 0, -1, -2, -3, -4, -5, -6, -7
 CLOSEST, ANY = 0, 1
 TRI_MT, TRI_WATERTIGHT = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -155,6 +155,7 @@ SYMBOLS = {
     "pgpu_build_svdags_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
     "pgpu_set_round_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_set_top_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "pgpu_debug_fail_sharded": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_set_svdag_defer": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "pgpu_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),
     "pgpu_lambert_bounce": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Rays), C.POINTER(Hits), C.c_size_t, C.POINTER(C.c_float), C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),

@@ -226,16 +226,17 @@ void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8T
     *blocks = std::max(1u, std::min(maxBlocks, wantBlocks));
 }
 
-int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks)
+int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& a, uint32_t* blocks, DeviceBuffer* spill)
 {
     planBvh8LaunchShape(c, depth, n_work, a, blocks);
     if (a.spill_entries) {
+        DeviceBuffer& sb = spill ? *spill : c->spill;
         const uint32_t raysPerBlock = 256u / a.lanes_per_ray;
         const size_t bytes = size_t(*blocks) * raysPerBlock * a.spill_entries * 8u;
-        const int rc = ensure(c, c->spill, bytes);
+        const int rc = ensure(c, sb, bytes);
         if (rc != PGPU_OK)
             return rc;
-        a.spill = static_cast<unsigned long long*>(c->spill.ptr);
+        a.spill = static_cast<unsigned long long*>(sb.ptr);
     }
     return PGPU_OK;
 }
@@ -267,7 +268,7 @@ int pgpu_init(int device_id, pgpu_ctx** out)
     if (e == hipSuccess)
         e = hipEventCreate(&c->ev1);
     if (e == hipSuccess)
-        e = hipMalloc(reinterpret_cast<void**>(&c->cursor), 256);
+        e = hipMalloc(reinterpret_cast<void**>(&c->cursor), 512); // (two sets of 8 cursors: c->cursor, c->cursor + 64)
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void**>(&c->statsDev), 64);
     if (e == hipSuccess)
@@ -332,7 +333,12 @@ void pgpu_shutdown(pgpu_ctx* c)
         (void)hipHostFree(c->roundCounts);
     if (c->copyStream)
         (void)hipStreamDestroy(c->copyStream);
-    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv })
+    if (c->auxStream)
+        (void)hipStreamDestroy(c->auxStream);
+    for (hipEvent_t e : { c->auxFork, c->auxJoin })
+        if (e)
+            (void)hipEventDestroy(e);
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv, &c->spillB })
         if (b->ptr)
             (void)hipFree(b->ptr);
     if (c->ev0)

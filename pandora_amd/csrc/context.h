@@ -84,6 +84,12 @@ struct pgpu_ctx {
     uint32_t* leafOwnerDev = nullptr;       // owner rank per batching point
     uint32_t* leafOwnerRemoteDev = nullptr; // the same with this rank's own points marked "no destination"
     DeviceBuffer shardWork, shardSend, shardRecv;
+    // pgpu_trace_sharded traces the rays parked at this rank's own batching points on a second stream, next to the record exchange
+    // and the trace of the received records: that launch has cursors and a stack-overflow buffer of its own
+    hipStream_t auxStream = nullptr;
+    hipEvent_t auxFork = nullptr, auxJoin = nullptr;
+    DeviceBuffer spillB;
+    int debugFailRound = -1; // pgpu_debug_fail_sharded: this rank fails (softly) when it has completed that many rounds
 
     // streamed leaves
     std::vector<StagedBvh> staged;               // indexed by bvh id; host == nullptr for HBM-resident ones
@@ -141,13 +147,18 @@ inline uint32_t deepestBvh(const pgpu_ctx* c)
 // Fills the stack window / spill fields of a bottom-level launch for trees of the given depth and returns
 // the grid size for n_work items (abi.hip).
 int readKernelStats(pgpu_ctx* c);
-int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
+// (spill: the overflow buffer to use and grow; default = the context's)
+int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks, DeviceBuffer* spill = nullptr);
 // The same plan without the spill buffer: args.spill stays null, args.spill_entries says how many 8-byte entries every
 // ray group of every block needs (the caller provides the memory).
 void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
 int initStaticScratch(pgpu_ctx* c); // noalloc.hip
 // route_abi.hip. instRows: closest-hit result rows have five values (the instance of the hit last), see launchPackResults
-int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows = false);
+// (cursor / spill: for a launch that runs next to another bottom-level launch of the same context; default = the context's)
+int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows = false,
+    uint32_t* cursor = nullptr, DeviceBuffer* spill = nullptr);
+// grows the scratch of traceLeafRecords (and the given overflow buffer) for up to k records, so that the call itself cannot fail on memory
+int reserveLeafRecords(pgpu_ctx* c, size_t k, DeviceBuffer* spill);
 void destroyComm(pgpu_ctx* c); // sharded_abi.hip
 }
 

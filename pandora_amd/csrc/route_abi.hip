@@ -13,21 +13,51 @@ uint32_t gridFor(const pgpu_ctx* c, size_t n) { return uint32_t(std::max<size_t>
 
 namespace pandora_hip {
 
-// The owner side of one round: k received records through the batching points they name -> k results, same order.
-// (Arguments are validated by the callers.)
-int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows)
+// scratch of traceLeafRecords for k records: SoA rays 8k, t/u/v 3k, obj/leaf/any 3k, workLeaf, sorted workRay/workBvh/workLeaf 3k, inst,
+// per-leaf count/start/fill, total
+struct LeafRecordsLayout {
+    size_t oSoa, oT, oU, oV, oObj, oLeaf, oAny, oWl, oSr, oSb, oSl, oInst, oCnt, oStart, oFill, oTotal, bytes;
+};
+static LeafRecordsLayout leafRecordsLayout(const pgpu_ctx* c, size_t k)
 {
-    // scratch: SoA rays 8k, t/u/v 3k, obj/leaf/any 3k, workLeaf, sorted workRay/workBvh/workLeaf 3k, per-leaf count/start/fill, total
     const size_t nl = c->top.n_leaves;
+    LeafRecordsLayout L {};
     size_t off = 0;
     auto carve = [&](size_t bytes) {
         const size_t at = off;
         off += alignUp(bytes);
         return at;
     };
-    const size_t oSoa = carve(k * 32), oT = carve(k * 4), oU = carve(k * 4), oV = carve(k * 4), oObj = carve(k * 4), oLeaf = carve(k * 4), oAny = carve(k * 4);
-    const size_t oWl = carve(k * 4), oSr = carve(k * 4), oSb = carve(k * 4), oSl = carve(k * 4), oInst = carve(k * 4);
-    const size_t oCnt = carve(nl * 4), oStart = carve(nl * 4), oFill = carve(nl * 4), oTotal = carve(256);
+    L.oSoa = carve(k * 32), L.oT = carve(k * 4), L.oU = carve(k * 4), L.oV = carve(k * 4), L.oObj = carve(k * 4), L.oLeaf = carve(k * 4), L.oAny = carve(k * 4);
+    L.oWl = carve(k * 4), L.oSr = carve(k * 4), L.oSb = carve(k * 4), L.oSl = carve(k * 4), L.oInst = carve(k * 4);
+    L.oCnt = carve(nl * 4), L.oStart = carve(nl * 4), L.oFill = carve(nl * 4), L.oTotal = carve(256);
+    L.bytes = off;
+    return L;
+}
+
+int reserveLeafRecords(pgpu_ctx* c, size_t k, DeviceBuffer* spill)
+{
+    int rc = ensure(c, c->routeWork, leafRecordsLayout(c, std::max<size_t>(k, 1)).bytes);
+    if (rc != PGPU_OK)
+        return rc;
+    Bvh8TraceArgs ba {};
+    ba.work_ray = reinterpret_cast<const uint32_t*>(c->routeWork.ptr); // (a work list: selects the layout the real launch will use)
+    ba.chunk = c->chunk;
+    uint32_t blocks = 1;
+    return planBvh8Launch(c, deepestBvh(c), std::max<size_t>(k, 1), ba, &blocks, spill);
+}
+
+// The owner side of one round: k received records through the batching points they name -> k results, same order.
+// (Arguments are validated by the callers.)
+int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows, uint32_t* cursor,
+    DeviceBuffer* spill)
+{
+    const size_t nl = c->top.n_leaves;
+    const LeafRecordsLayout L = leafRecordsLayout(c, k);
+    const size_t off = L.bytes, oSoa = L.oSoa, oT = L.oT, oU = L.oU, oV = L.oV, oObj = L.oObj, oLeaf = L.oLeaf, oAny = L.oAny, oWl = L.oWl, oSr = L.oSr,
+                 oSb = L.oSb, oSl = L.oSl, oInst = L.oInst, oCnt = L.oCnt, oStart = L.oStart, oFill = L.oFill, oTotal = L.oTotal;
+    if (!cursor)
+        cursor = c->cursor;
     int rc = ensure(c, c->routeWork, off);
     if (rc != PGPU_OK)
         return rc;
@@ -75,7 +105,7 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
         ba.inst_out = inst; // (written by hits only: a miss row's value is never read)
         HIP_TRY(c, hipMemsetAsync(inst, 0xFF, k * 4, stream));
     }
-    ba.cursor = c->cursor;
+    ba.cursor = cursor;
     ba.chunk = c->chunk;
     ba.init_miss = 0;
     ba.stats = c->stats ? c->statsDev : nullptr;
@@ -85,9 +115,9 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
     HIP_TRY(c, hipMemsetAsync(sb, 0xFF, k * 4, stream));
     HIP_TRY(c, hipMemsetAsync(sr, 0, k * 4, stream));
     HIP_TRY(c, launchBinByLeaf(nullptr, wl, uint32_t(k), uint32_t(nl), start, fill, c->top.leaves, sr, sb, sl, blocks, stream));
-    HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+    HIP_TRY(c, hipMemsetAsync(cursor, 0, 256, stream));
     uint32_t nBlocks = 1;
-    rc = planBvh8Launch(c, deepest, k, ba, &nBlocks);
+    rc = planBvh8Launch(c, deepest, k, ba, &nBlocks, spill);
     if (rc != PGPU_OK)
         return rc;
     HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, nBlocks, stream));

@@ -17,6 +17,7 @@
 // until the matrix is all zero. The transport (three collectives) is RCCL -- grouped ncclSend / ncclRecv, one message per
 // peer and direction, i.e. one per xGMI link -- or supplied by the caller.
 #include "context.h"
+#include "trace_ranges.h"
 #include <algorithm>
 #include <cstring>
 #include <dlfcn.h>
@@ -495,33 +496,96 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     uint32_t nActive = uint32_t(n);
     const uint32_t* active = nullptr; // round 0: every ray, identity order
     int flip = 0;
-    // Result rows: {hit}, {t, obj, u, v}, or with a fifth value -- the instance a hit went through -- when any rank of the job
-    // holds instanced leaves. Every rank must use the same row size: the flag travels with the first round's count matrix.
+
+    // ---- Failures. A rank that leaves the loop alone strands its peers inside the round's collectives. So (1) everything a round
+    // could fail to allocate is reserved before the first round, from what the ranks tell each other up front; (2) a rank that
+    // fails -- there, or in a launch later on -- keeps taking part: it raises a flag that travels with the next count rows, and
+    // every rank leaves the loop in that same round (the failing rank with its own error, the others with "a peer failed").
+    // Only a failing transport call ends the loop at once: there is nothing left to tell the peers with.
+    int pending = PGPU_OK; // this rank's first soft failure
+    auto soft = [&](int code) {
+        if (code != PGPU_OK && pending == PGPU_OK)
+            pending = code;
+        return code == PGPU_OK;
+    };
+    auto softHip = [&](hipError_t e, const char* what) { return soft(e == hipSuccess ? PGPU_OK : fail(c, PGPU_ERR_HIP, what, e)); };
+
+    // Up front, one all-gather: every rank's ray count and whether it holds instanced leaves. Result rows are {hit}, {t, obj, u, v},
+    // or with a fifth value -- the instance a hit went through -- when any rank of the job holds instances: every rank must use the
+    // same row size. No round can deliver more records to a rank than the other ranks have rays.
     size_t resultBytes = closest ? 16 : 4;
-    bool instRows = false;
+    bool instRows = c->hasInstances;
+    size_t recvCap = 1;
+    if (world > 1) {
+        const uint32_t mine[2] = { uint32_t(n), c->hasInstances ? 1u : 0u };
+        HIP_TRY(c, hipMemcpyAsync(dCounts, mine, 8, hipMemcpyHostToDevice, stream));
+        if (c->comm->transport.allgather_u32(c->comm->transport.user, dCounts, dMatrix, 2, stream) != 0)
+            return transportFail(c, "pgpu_trace_sharded: all-gather of the ray counts failed");
+        HIP_TRY(c, hipMemcpyAsync(gathered.data(), dMatrix, size_t(world) * 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        uint64_t others = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            if (r != rank)
+                others += gathered[2u * r];
+            instRows = instRows || gathered[2u * r + 1u] != 0u;
+        }
+        recvCap = size_t(std::max<uint64_t>(others, 1));
+        // (soft: a rank that cannot get the memory says so in the first round's rows)
+        if (soft(ensure(c, c->shardRecv, alignUp(recvCap * 36) + alignUp(recvCap * 20))))
+            soft(reserveLeafRecords(c, recvCap, &c->spill));
+        if (!c->auxStream)
+            softHip(hipStreamCreateWithFlags(&c->auxStream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        for (hipEvent_t* e : { &c->auxFork, &c->auxJoin })
+            if (!*e)
+                softHip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreateWithFlags");
+    }
+    if (closest)
+        resultBytes = instRows ? 20 : 16;
+    {
+        // the in-place trace of the rays parked at this rank's own points: at most n work items, overflow buffer of its own
+        Bvh8TraceArgs probe = ba;
+        probe.work_ray = dWork[0];
+        probe.chunk = c->chunk;
+        uint32_t blocks = 1;
+        soft(planBvh8Launch(c, deepest, nb, probe, &blocks, &c->spillB));
+    }
+    float* const dRecvRec = static_cast<float*>(c->shardRecv.ptr);
+    float* const dResOut = c->shardRecv.ptr ? reinterpret_cast<float*>(static_cast<unsigned char*>(c->shardRecv.ptr) + alignUp(recvCap * 36)) : nullptr;
+    uint32_t* const cursorLocal = c->cursor + 64; // (the record trace keeps c->cursor)
     // a record carries the ray with tfar = its current t (closest hit), so the owner only reports something closer
     const float* recordSrc[8] = { rp[0], rp[1], rp[2], rp[3], rp[4], rp[5], rp[6], closest ? hits->t : rp[7] };
+    int peerFailed = 0;
     for (;;) {
-        HIP_TRY(c, hipMemsetAsync(dLeafCount, 0, nl * 4, stream));
-        HIP_TRY(c, hipMemsetAsync(dCounts, 0, 512, stream)); // counts per owner, then this rank's "holds instances" flag
-        HIP_TRY(c, hipMemsetAsync(dFill, 0, 256, stream));
+        const TraceRange roundRange("sharded round");
         uint32_t* const workOut = dWork[flip];
-        if (nActive) {
+        if (c->debugFailRound >= 0 && rounds == uint64_t(c->debugFailRound))
+            soft(fail(c, PGPU_ERR_HIP, "pgpu_trace_sharded: failure injected by pgpu_debug_fail_sharded"));
+        bool ok = pending == PGPU_OK;
+        ok = ok && softHip(hipMemsetAsync(dLeafCount, 0, nl * 4, stream), "hipMemsetAsync");
+        ok = ok && softHip(hipMemsetAsync(dCounts, 0, 512, stream), "hipMemsetAsync"); // counts per owner, then this rank's failure flag
+        ok = ok && softHip(hipMemsetAsync(dFill, 0, 256, stream), "hipMemsetAsync");
+        if (ok && nActive) {
+            const TraceRange r_("sharded round: top-level episode + bin + count per owner");
             ta.active = active;
             ta.n_active = nActive;
             ta.may_park = rounds < nl ? 1u : 0u; // a ray pauses at most once per batching point
             ta.ray_aos = active ? dRayAos : nullptr; // the first episode (identity list) reads the caller's arrays and writes the records
             ta.ray_aos_out = active ? nullptr : dRayAos;
-            HIP_TRY(c, launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u)), stream));
-            HIP_TRY(c, launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), dTotal, stream));
-            HIP_TRY(c, launchBinByLeaf(active, dParked, nActive, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workOut, dWorkBvh, dWorkLeaf,
-                           gridFor(c, nActive), stream));
-            HIP_TRY(c, launchRouteCount(dParked, nActive, c->leafOwnerDev, uint32_t(nl), world, dCounts, gridFor(c, nActive), stream));
+            ok = softHip(launchTopTraverse(ta, kind, std::max(1u, std::min(topMaxBlocks, (nActive + 255u) / 256u)), stream), "top-level episode")
+                && softHip(launchLeafScan(dLeafCount, dLeafStart, dLeafFill, uint32_t(nl), dTotal, stream), "leaf scan")
+                && softHip(launchBinByLeaf(active, dParked, nActive, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workOut, dWorkBvh, dWorkLeaf,
+                               gridFor(c, nActive), stream), "binning")
+                && softHip(launchRouteCount(dParked, nActive, c->leafOwnerDev, uint32_t(nl), world, dCounts, gridFor(c, nActive), stream), "route count");
         }
         // the one host synchronisation of the round: who sends how many records to whom (row r = rank r's counts per owner;
-        // the diagonal counts the rays that parked at their own rank's points; behind each row: does that rank hold instances?)
-        const uint32_t hasInst = c->hasInstances ? 1u : 0u;
-        HIP_TRY(c, hipMemcpyAsync(dCounts + world, &hasInst, 4, hipMemcpyHostToDevice, stream));
+        // the diagonal counts the rays that parked at their own rank's points; behind each row: has that rank failed?)
+        if (pending != PGPU_OK) {
+            // (a failed rank promises nothing: a zero row with the flag up)
+            std::vector<uint32_t> row(world + 1u, 0u);
+            row[world] = 1u;
+            (void)hipMemcpyAsync(dCounts, row.data(), row.size() * 4, hipMemcpyHostToDevice, stream);
+            (void)hipStreamSynchronize(stream);
+        }
         if (world > 1) {
             if (c->comm->transport.allgather_u32(c->comm->transport.user, dCounts, dMatrix, world + 1u, stream) != 0)
                 return transportFail(c, "pgpu_trace_sharded: all-gather of the record counts failed");
@@ -534,10 +598,10 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         for (uint32_t r = 0; r < world; ++r) {
             for (uint32_t p = 0; p < world; ++p)
                 total += matrix[size_t(r) * world + p] = gathered[size_t(r) * (world + 1u) + p];
-            instRows = instRows || gathered[size_t(r) * (world + 1u) + world] != 0u;
+            peerFailed += (r != rank && gathered[size_t(r) * (world + 1u) + world] != 0u) ? 1 : 0;
         }
-        if (closest)
-            resultBytes = instRows ? 20 : 16;
+        if (pending != PGPU_OK || peerFailed)
+            break; // every rank sees the same flags: nobody is left inside a collective
         if (total == 0)
             break;
         ++rounds;
@@ -552,48 +616,75 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         }
         leafVisits += parked;
         routed += sendTotal;
-        // rays parked at this rank's own batching points: traced in place from the binned list (the kernel skips the work
-        // items whose batching point has no BVH here -- those travel as records below)
+        if (recvTotal > recvCap) // (cannot happen: the other ranks do not have that many rays; a wrong count must not overrun the buffer)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_trace_sharded: a peer announced more records than it has rays");
+        // Rays parked at this rank's own batching points: traced in place from the binned list (the kernel skips the work items
+        // whose batching point has no BVH here -- those travel as records). With peers, on a second stream: it touches other rays'
+        // results than the records and their merge do, so it runs next to the exchange and the trace of the received records.
+        const bool fork = world > 1 && c->auxStream && c->auxFork && c->auxJoin && (sendTotal || recvTotal);
+        hipStream_t localStream = fork ? c->auxStream : stream;
+        bool forked = false;
         if (parked) {
-            HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+            const TraceRange r_("sharded round: in-place trace of the rays parked at this rank's points");
+            if (fork) {
+                forked = softHip(hipEventRecord(c->auxFork, stream), "hipEventRecord") && softHip(hipStreamWaitEvent(c->auxStream, c->auxFork, 0), "hipStreamWaitEvent");
+                if (!forked)
+                    localStream = stream;
+            }
             ba.work_ray = workOut;
             ba.n_work = parked;
             ba.chunk = c->chunk;
             ba.ray_aos = dRayAos;
+            ba.cursor = cursorLocal;
             uint32_t blocks = 1;
-            rc = planBvh8Launch(c, deepest, parked, ba, &blocks);
-            if (rc != PGPU_OK)
-                return rc;
-            HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+            if (softHip(hipMemsetAsync(cursorLocal, 0, 256, localStream), "hipMemsetAsync") && soft(planBvh8Launch(c, deepest, parked, ba, &blocks, &c->spillB)))
+                softHip(launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, localStream), "bottom-level trace");
+            if (forked)
+                softHip(hipEventRecord(c->auxJoin, c->auxStream), "hipEventRecord");
         }
         if (world > 1) {
-            if (sendTotal)
-                HIP_TRY(c, launchRouteScatter(recordSrc, active, dParked, nActive, c->leafOwnerRemoteDev, uint32_t(nl), world, starts.data(), dFill, dSendRec, dSlot,
-                               dSentLeaf, gridFor(c, nActive), stream));
-            rc = ensure(c, c->shardRecv, alignUp(size_t(std::max(recvTotal, 1u)) * 36) + alignUp(size_t(std::max(recvTotal, 1u)) * 20));
-            if (rc != PGPU_OK)
-                return rc;
-            float* dRecvRec = static_cast<float*>(c->shardRecv.ptr);
-            float* dResOut = reinterpret_cast<float*>(static_cast<unsigned char*>(c->shardRecv.ptr) + alignUp(size_t(std::max(recvTotal, 1u)) * 36));
-            // (closest hit: a record carries the ray's current t as tfar -- the in-place trace above touches other rays only)
-            if (c->comm->transport.exchange(c->comm->transport.user, dSendRec, sendCounts.data(), dRecvRec, recvCounts.data(), 36, stream) != 0)
-                return transportFail(c, "pgpu_trace_sharded: record exchange failed");
-            if (recvTotal) {
-                rc = traceLeafRecords(c, kind, tri_mode, dRecvRec, recvTotal, dResOut, stream, instRows);
-                if (rc != PGPU_OK)
-                    return rc;
+            // (from here to the end of the round a failure is soft: the exchanges are still called with the promised counts)
+            if (sendTotal) {
+                const TraceRange r_("sharded round: pack records");
+                softHip(launchRouteScatter(recordSrc, active, dParked, nActive, c->leafOwnerRemoteDev, uint32_t(nl), world, starts.data(), dFill, dSendRec, dSlot,
+                            dSentLeaf, gridFor(c, nActive), stream), "record scatter");
             }
-            if (c->comm->transport.exchange(c->comm->transport.user, dResOut, recvCounts.data(), dResBack, sendCounts.data(), resultBytes, stream) != 0)
-                return transportFail(c, "pgpu_trace_sharded: result exchange failed");
+            // (closest hit: a record carries the ray's current t as tfar -- the in-place trace touches other rays only)
+            {
+                const TraceRange r_("sharded round: record exchange (all-to-all)");
+                if (c->comm->transport.exchange(c->comm->transport.user, dSendRec, sendCounts.data(), dRecvRec, recvCounts.data(), 36, stream) != 0)
+                    return transportFail(c, "pgpu_trace_sharded: record exchange failed");
+            }
+            if (recvTotal) {
+                const TraceRange r_("sharded round: trace of the received records");
+                soft(traceLeafRecords(c, kind, tri_mode, dRecvRec, recvTotal, dResOut, stream, instRows, c->cursor, &c->spill));
+            }
+            {
+                const TraceRange r_("sharded round: result exchange (all-to-all)");
+                if (c->comm->transport.exchange(c->comm->transport.user, dResOut, recvCounts.data(), dResBack, sendCounts.data(), resultBytes, stream) != 0)
+                    return transportFail(c, "pgpu_trace_sharded: result exchange failed");
+            }
+            if (forked) // the merge and the next episode see the in-place trace's results
+                softHip(hipStreamWaitEvent(stream, c->auxJoin, 0), "hipStreamWaitEvent");
             if (sendTotal)
-                HIP_TRY(c, launchMergeResults(sendTotal, dResBack, dSlot, dSentLeaf, closest ? hits->t : nullptr, closest ? hits->obj : nullptr,
-                               closest ? hits->leaf : nullptr, closest ? hits->u : nullptr, closest ? hits->v : nullptr, closest ? nullptr : any_hit,
-                               gridFor(c, sendTotal), stream, dInst, closest && instRows ? 5u : 4u));
+                softHip(launchMergeResults(sendTotal, dResBack, dSlot, dSentLeaf, closest ? hits->t : nullptr, closest ? hits->obj : nullptr,
+                            closest ? hits->leaf : nullptr, closest ? hits->u : nullptr, closest ? hits->v : nullptr, closest ? nullptr : any_hit,
+                            gridFor(c, sendTotal), stream, dInst, closest && instRows ? 5u : 4u), "result merge");
             exchangeBytes += (uint64_t(sendTotal) + recvTotal) * (36 + resultBytes);
         }
         active = workOut;
         nActive = parked;
         flip ^= 1;
+    }
+    if (c->auxStream)
+        (void)hipStreamSynchronize(c->auxStream);
+    if (pending != PGPU_OK) {
+        (void)hipStreamSynchronize(stream);
+        return pending; // (pgpu_last_error holds what failed)
+    }
+    if (peerFailed) {
+        (void)hipStreamSynchronize(stream);
+        return fail(c, PGPU_ERR_PEER, "pgpu_trace_sharded: another rank of the job failed; every rank left the loop in the same round");
     }
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     c->timingStale = false;
@@ -616,6 +707,14 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     }
     if (counters)
         *counters = c->counters;
+    return PGPU_OK;
+}
+
+int pgpu_debug_fail_sharded(pgpu_ctx* c, int after_rounds)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    c->debugFailRound = after_rounds;
     return PGPU_OK;
 }
 

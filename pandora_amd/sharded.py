@@ -42,6 +42,45 @@ def assign_leaves(weights, world: int) -> np.ndarray:
     return owner
 
 
+def assign_leaves_contiguous(weights_by_slot, world: int) -> np.ndarray:
+    """Owner rank per batching point by position in the top level: the leaf slots of the PauseableBVH4 are in depth-first
+    order (pauseable_bvh4.h:461-482), so neighbouring slots are neighbouring subtrees, i.e. neighbouring space. The slot
+    sequence is cut into `world` runs of about equal weight: a ray that leaves one batching point mostly enters one a few slots
+    away -- with this table that is usually the same rank's. (assign_leaves balances better and scatters neighbours over all
+    ranks.) weights_by_slot: one weight per leaf SLOT. Returns the owner per slot. Deterministic."""
+    w = np.asarray(weights_by_slot, np.float64)
+    if w.size == 0:
+        return np.zeros(0, np.int64)
+    total = float(w.sum())
+    if total <= 0.0:
+        return (np.arange(w.size) * world // w.size).astype(np.int64)
+    mid = np.cumsum(w) - 0.5 * w  # a point belongs to the run its centre of weight falls into
+    return np.minimum(world - 1, (mid * world / total).astype(np.int64))
+
+
+def home_ranks_by_origin(leaf_bounds_by_slot, owner_by_slot, rays) -> np.ndarray:
+    """Home rank per ray = the owner of the batching point its origin lies in (the smallest such box; the nearest box centre for
+    an origin outside all of them). What a distributed integrator does when it spawns a bounce ray at a hit point: the ray
+    starts where its geometry is. With owners that are contiguous in the top level (assign_leaves_contiguous) most of a ray's
+    batching-point visits then stay on its home rank. leaf_bounds_by_slot: [n_leaves, 6] (min, max) in slot order; rays [8, n]."""
+    b = np.asarray(leaf_bounds_by_slot, np.float32)
+    o = np.asarray(rays, np.float32)[0:3].T
+    owner = np.asarray(owner_by_slot, np.int64)
+    vol = np.prod(np.maximum(b[:, 3:] - b[:, :3], 1e-12).astype(np.float64), axis=1)
+    best = np.full(o.shape[0], -1, np.int64)
+    best_vol = np.full(o.shape[0], np.inf)
+    for s in np.argsort(vol):  # (n_leaves passes over the rays: fine for the sizes this is used at)
+        inside = np.all((o >= b[s, :3]) & (o <= b[s, 3:]), axis=1) & (vol[s] < best_vol)
+        best[inside] = s
+        best_vol[inside] = vol[s]
+    out = best < 0
+    if out.any():
+        centre = 0.5 * (b[:, :3] + b[:, 3:])
+        for i in np.nonzero(out)[0]:
+            best[i] = int(np.argmin(((centre - o[i]) ** 2).sum(axis=1)))
+    return owner[best]
+
+
 def reduce_job(elapsed_s: float, n_units: int, device=None):
     """Whole-job figures of a run in which every rank processed its own units (rays) between two barriers:
     (slowest rank's time, units summed over ranks). Works on any backend (nccl needs `device`)."""

@@ -16,7 +16,8 @@ from pandora_amd import sharded  # noqa: E402
 
 def main():
     # mode 0 / 1: Python loop (torch / device records), 2: pgpu_trace_sharded, 3: pgpu_trace_sharded on the instanced landscape,
-    # 4: pgpu_trace_sharded on a city whose BVHs every rank builds for its own batching points only
+    # 4: pgpu_trace_sharded on a city whose BVHs every rank builds for its own batching points only, 5: the same with owners
+    # contiguous in the top level and the rays at home where they start
     out_dir, kind, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     device_records = bool(mode)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -26,9 +27,12 @@ def main():
         if mode == 3:
             instanced_landscape(out_dir, kind, rank, world, dev)
             return
-        if mode == 4:  # a city of ~0.35 M triangles in ~60 batching points, every rank building only its own (as bench.py does)
+        homed = False
+        if mode in (4, 5):  # a city of ~0.35 M triangles in ~60 batching points, every rank building only its own (as bench.py does)
+            # 5: owners contiguous in the top level's leaf order, and every ray at home on the rank that owns the point it starts in
+            homed = mode == 5
+            mesh, tl, owner_by_input = city_scene(world, rank, contiguous=homed)
             mode = 2
-            mesh, tl, owner_by_input = city_scene(world, rank)
         else:
             mesh = pa.scenes.g_small()
             tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=32)
@@ -41,7 +45,14 @@ def main():
             tl.upload(ctx, ctx.upload_mesh(part_pos, part_idx), resident=(owner == rank), prim_remap=remap)
         else:
             tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), resident=(owner == rank))
-        rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
+        rays = np.load(os.path.join(out_dir, "rays.npy"))
+        if homed:
+            slot_bounds = tl.leaf_bounds[np.asarray(tl.top.leaf_order, np.int64)]
+            mine = np.nonzero(sharded.home_ranks_by_origin(slot_bounds, owner, rays) == rank)[0]
+            np.save(os.path.join(out_dir, f"ids{rank}.npy"), mine)
+            rays = rays[:, mine]
+        else:
+            rays = rays[:, rank::world]
         d_rays = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)
         if mode == 2:
             # the whole loop inside the library; the collectives go through host memory + gloo (two ranks share one GPU, which RCCL refuses)
@@ -49,6 +60,23 @@ def main():
             ctx.comm_selftest()
             ctx.set_leaf_owners(owner)
             ctx.set_svdag_policy(int(os.environ.get("PANDORA_TEST_SVDAG_POLICY", "0")))
+            fail_spec = os.environ.get("PANDORA_TEST_FAIL", "")  # "<rank>:<completed rounds>": that rank's loop fails there
+            if fail_spec:
+                bad_rank, after = (int(x) for x in fail_spec.split(":"))
+                if rank == bad_rank:
+                    ctx.debug_fail_sharded(after)
+                try:
+                    ctx.trace_sharded(d_rays, kind=kind)
+                    code = 0
+                except pa.capi.PandoraError as e:
+                    code = e.code
+                np.savez(os.path.join(out_dir, f"r{rank}.npz"), code=code)
+                # the communicator is still usable: the ranks left the loop in the same round, nobody is inside a collective
+                ctx.debug_fail_sharded(-1)
+                st, cnt = ctx.trace_sharded(d_rays, kind=kind)
+                np.savez(os.path.join(out_dir, f"again{rank}.npz"), **{k: v.cpu().numpy() for k, v in st.items()})
+                ctx.close()
+                return
             st, cnt = ctx.trace_sharded(d_rays, kind=kind)
             info = {"routed": cnt["records_routed"], "rounds": cnt["rounds"], "leaf_visits": cnt["leaf_visits"]}
             film = torch.full((5, 3), rank + 1, dtype=torch.int64, device=dev)
@@ -70,13 +98,18 @@ def city_mesh():
     return pa.scenes.g_city(4, 20000)
 
 
-def city_scene(world, rank):
+def city_scene(world, rank, contiguous=False):
     """(mesh, two-level scene with the BVHs of `rank`'s batching points only -- all of them when rank is None --, owner per input group)"""
     mesh = city_mesh()
     box = {}
 
-    def mine(sizes):
-        box["owner"] = sharded.assign_leaves(sizes, world)
+    def mine(sizes, top):
+        if contiguous:  # runs of the top level's leaf order (neighbouring space), balanced by triangle count
+            order = np.asarray(top.leaf_order, np.int64)
+            box["owner"] = np.empty(len(sizes), np.int64)
+            box["owner"][order] = sharded.assign_leaves_contiguous(np.asarray(sizes)[order], world)
+        else:
+            box["owner"] = sharded.assign_leaves(sizes, world)
         return np.ones(len(sizes), bool) if rank is None else box["owner"] == rank
 
     tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 8192, svdag_res=32, build_group=mine)

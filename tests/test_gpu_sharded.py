@@ -140,6 +140,34 @@ def test_two_processes_sharded_leaves(scene, kind, device_records):
     assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
 
 
+@pytest.mark.parametrize("after_rounds", [0, 1])
+def test_a_failing_rank_takes_its_peers_out_of_the_loop_together(scene, after_rounds):
+    """Rank 1 fails inside pgpu_trace_sharded (before the first round / after one round, the way a failed launch or allocation
+    would): it must still take part in the round's collectives, rank 0 must come back with PGPU_ERR_PEER instead of waiting
+    inside an all-to-all, and the same communicator must serve a complete trace right afterwards."""
+    ctx, mesh, tl = scene
+    rays = _rays(mesh)
+    want, _ = ctx.trace(rays)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "rays.npy"), rays)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PANDORA_TEST_FAIL=f"1:{after_rounds}")
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(pa.capi.CLOSEST), "2"], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=120)[0].decode(errors="replace") for p in procs]  # (a stranded rank would run into this timeout)
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+        codes = [int(np.load(os.path.join(d, f"r{r}.npz"))["code"]) for r in range(2)]
+        again = [dict(np.load(os.path.join(d, f"again{r}.npz"))) for r in range(2)]
+    assert codes == [pa.capi.ERR_PEER, pa.capi.ERR_HIP], codes
+    for r, p in enumerate(again):
+        for k in ("t", "obj", "leaf", "u", "v", "visits"):
+            assert np.array_equal(_bits(p[k]), _bits(want[k])[r::2]), f"after the failure, rank {r}: {k}"
+
+
 def test_two_processes_sharded_svdag_only_for_remote_points(scene):
     """pgpu_set_svdag_policy(ctx, 1) on two ranks: a rank tests the SVDAG of the other rank's batching points (a miss saves a
     record's round trip) and visits its own without the test. Same hits as one context; fewer SVDAG tests."""
@@ -167,7 +195,8 @@ def test_two_processes_sharded_svdag_only_for_remote_points(scene):
     assert sum(int(p["leaf_visits"]) for p in parts) >= wcnt["leaf_visits"]
 
 
-def test_four_processes_sharded_city():
+@pytest.mark.parametrize("mode", [4, 5], ids=["lpt_owners_interleaved_rays", "contiguous_owners_rays_at_home"])
+def test_four_processes_sharded_city(mode):
     """Four ranks (sharing the one GPU, records through host memory) on a city of ~60 batching points, each rank building and
     uploading only its own points' BVHs and triangles, 150 K shuffled diffuse rays: several rounds with thousands of records
     per peer and direction, buffers that grow -- results equal one context's pgpu_trace bit for bit."""
@@ -195,15 +224,26 @@ def test_four_processes_sharded_city():
         procs = []
         for r in range(4):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(pa.capi.CLOSEST), "4"], env=env,
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(pa.capi.CLOSEST), str(mode)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
         parts = [dict(np.load(os.path.join(d, f"r{r}.npz"))) for r in range(4)]
-    assert sum(int(p["routed"]) for p in parts) > rays.shape[1] // 2
+        ids = [np.load(os.path.join(d, f"ids{r}.npy")) if mode == 5 else np.arange(r, rays.shape[1], 4) for r in range(4)]
+    routed, visits = sum(int(p["routed"]) for p in parts), sum(int(p["leaf_visits"]) for p in parts)
+    frac = routed / visits
+    print(f"records_routed_fraction, 4 ranks, mode {mode}: {frac:.3f} ({routed} of {visits} batching-point visits)")
+    if mode == 4:
+        # owners spread by size (LPT), rays dealt round-robin: a visit is local with probability 1 / 4
+        assert 0.65 < frac < 0.85
+    else:
+        # owners = contiguous runs of the top level's leaf order, rays at home where they start: the first visit is local, and most
+        # of the later ones (a ray that leaves a batching point enters a neighbour) -- well below (N - 1) / N = 0.75
+        assert frac < 0.25 and np.array_equal(np.sort(np.concatenate(ids)), np.arange(rays.shape[1]))
+        assert min(i.size for i in ids) > 0
     for r, p in enumerate(parts):
         for k in ("t", "obj", "leaf", "u", "v", "visits"):
-            assert np.array_equal(_bits(p[k]), _bits(want[k])[r::4]), f"rank {r}: {k}"
+            assert np.array_equal(_bits(p[k]), _bits(want[k])[ids[r]]), f"rank {r}: {k}"
     assert sum(int(p["leaf_visits"]) for p in parts) == wcnt["leaf_visits"]
     assert sum(int(p["svdag_tests"]) for p in parts) == wcnt["svdag_tests"]
     assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
