@@ -186,9 +186,10 @@ int pgpu_stage_bvh8_instanced(pgpu_ctx*, const void* nodes256, size_t n_nodes, c
  * most rays per byte are taken, one cache-full of them). Results do not depend on any of this; pgpu_counters.rounds does.
  * pgpu_set_leaf_cache sets the HBM budget of the cache in bytes (0 = room for every staged BVH); it must
  * hold the largest image. Staged ids share the id space of uploaded ones but
- * are valid only as pgpu_leaf.bvh_id for pgpu_trace: pgpu_trace_bvh8, pgpu_trace_leaves and pgpu_trace_leaf_records return
- * PGPU_ERR_NO_SCENE on a context that holds staged BVHs. Staging another BVH (or pgpu_set_leaf_cache) empties the cache;
- * it is rebuilt by the next pgpu_trace. */
+ * are valid only as pgpu_leaf.bvh_id for pgpu_trace and pgpu_trace_sharded (where every point that has work in a round is loaded
+ * in that round -- rays are not held back there, a record's result goes home in the round it arrived): pgpu_trace_bvh8,
+ * pgpu_trace_leaves and pgpu_trace_leaf_records return PGPU_ERR_NO_SCENE on a context that holds staged BVHs. Staging another
+ * BVH (or pgpu_set_leaf_cache) empties the cache; it is rebuilt by the next trace. */
 int pgpu_stage_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_leaf_indices,
     uint32_t root_handle, const pgpu_leafobj* objs, size_t n_objs, uint32_t* bvh_id);
 int pgpu_set_leaf_cache(pgpu_ctx*, size_t bytes);
@@ -262,7 +263,7 @@ typedef struct {
     uint64_t leaf_visits;               /* rays parked at batching points, summed */
     uint64_t rounds;                    /* wavefront rounds the two-level loop needed */
     uint64_t inner_visits, leaf_pops, tri_tests; /* filled only when stats are enabled */
-    uint64_t leaf_loads, streamed_bytes; /* staged BVHs copied into the HBM leaf cache by the last pgpu_trace */
+    uint64_t leaf_loads, streamed_bytes; /* staged BVHs copied into the HBM leaf cache by the last pgpu_trace / pgpu_trace_sharded */
     uint64_t wave_steps, leaf_passes, refill_passes; /* kernel-loop diagnostics (stats enabled): wavefront iterations,
                                                        * those that ran the triangle code, those that fetched new rays */
     uint64_t records_routed, exchange_bytes; /* pgpu_trace_sharded: records sent to other ranks; bytes sent + received */

@@ -153,6 +153,11 @@ int planBvh8Launch(pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& ar
 // ray group of every block needs (the caller provides the memory).
 void planBvh8LaunchShape(const pgpu_ctx* c, uint32_t depth, size_t n_work, Bvh8TraceArgs& args, uint32_t* blocks);
 int initStaticScratch(pgpu_ctx* c); // noalloc.hip
+// top_abi.hip: the HBM cache of staged BVHs (built on first use), and the bottom level over a work list sorted by batching point
+// when some BVHs are staged -- launch groups by what fits the cache together (see there)
+int prepareLeafCache(pgpu_ctx* c);
+int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& visitOrder, const uint32_t* leafStart,
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream);
 // route_abi.hip. instRows: closest-hit result rows have five values (the instance of the hit last), see launchPackResults
 // (cursor / spill: for a launch that runs next to another bottom-level launch of the same context; default = the context's)
 int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows = false,

@@ -2,6 +2,7 @@
 #include "context.h"
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 using namespace pandora_hip;
 
@@ -115,12 +116,30 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
     HIP_TRY(c, hipMemsetAsync(sb, 0xFF, k * 4, stream));
     HIP_TRY(c, hipMemsetAsync(sr, 0, k * 4, stream));
     HIP_TRY(c, launchBinByLeaf(nullptr, wl, uint32_t(k), uint32_t(nl), start, fill, c->top.leaves, sr, sb, sl, blocks, stream));
-    HIP_TRY(c, hipMemsetAsync(cursor, 0, 256, stream));
-    uint32_t nBlocks = 1;
-    rc = planBvh8Launch(c, deepest, k, ba, &nBlocks, spill);
-    if (rc != PGPU_OK)
-        return rc;
-    HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, nBlocks, stream));
+    if (c->nStaged > 0) {
+        // some batching points are staged in host memory: the sorted list is traced in launch groups of what fits the HBM cache
+        // together (top_abi.hip); the per-point counts cut the list, so the host has to see them
+        std::vector<uint32_t> hCount(nl), hStart(nl), order;
+        HIP_TRY(c, hipMemcpyAsync(hCount.data(), cnt, nl * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        uint32_t run = 0;
+        for (size_t l = 0; l < nl; ++l) {
+            hStart[l] = run;
+            run += hCount[l];
+            if (hCount[l] != 0u)
+                order.push_back(uint32_t(l));
+        }
+        rc = traceLeafGroups(c, ba, kind, tri_mode, deepest, order, hStart.data(), hCount.data(), cursor, spill, stream);
+        if (rc != PGPU_OK)
+            return rc;
+    } else {
+        HIP_TRY(c, hipMemsetAsync(cursor, 0, 256, stream));
+        uint32_t nBlocks = 1;
+        rc = planBvh8Launch(c, deepest, k, ba, &nBlocks, spill);
+        if (rc != PGPU_OK)
+            return rc;
+        HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, nBlocks, stream));
+    }
     HIP_TRY(c, launchPackResults(uint32_t(k), t, obj, u, v, closest ? nullptr : any, results, blocks, stream, instRows && closest ? inst : nullptr));
     return PGPU_OK;
 }

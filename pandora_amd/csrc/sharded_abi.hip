@@ -360,8 +360,6 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: no top-level structure uploaded");
     if (c->leafOwnerHost.size() != c->top.n_leaves)
         return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: no owner table for this top level (pgpu_set_leaf_owners)");
-    if (c->nStaged > 0)
-        return fail(c, PGPU_ERR_NO_SCENE, "pgpu_trace_sharded: this context holds BVHs staged in host memory (pgpu_stage_bvh8); only pgpu_trace streams them");
     if (kind != PGPU_CLOSEST && kind != PGPU_ANY)
         return fail(c, PGPU_ERR_INVALID, "pgpu_trace_sharded: kind must be PGPU_CLOSEST or PGPU_ANY");
     if (tri_mode != PGPU_TRI_MT && tri_mode != PGPU_TRI_WATERTIGHT)
@@ -502,6 +500,14 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     // fails -- there, or in a launch later on -- keeps taking part: it raises a flag that travels with the next count rows, and
     // every rank leaves the loop in that same round (the failing rank with its own error, the others with "a peer failed").
     // Only a failing transport call ends the loop at once: there is nothing left to tell the peers with.
+    // Batching points staged in host memory (pgpu_stage_bvh8; BASELINE configs[4]): the owner streams their images through its HBM
+    // cache as pgpu_trace does -- both of a round's bottom-level passes (the rays parked here in place, the received records) run
+    // as launch groups of what fits the cache together. Every point that has work in a round is loaded in that round: rays are
+    // not held back for fuller queues here (pgpu_set_leaf_hold applies to pgpu_trace only), a record's result goes home in the
+    // round it arrived.
+    const bool streamed = c->nStaged > 0;
+    c->counters.leaf_loads = c->counters.streamed_bytes = 0;
+    std::vector<uint32_t> hLeafStart, visitOrder;
     int pending = PGPU_OK; // this rank's first soft failure
     auto soft = [&](int code) {
         if (code != PGPU_OK && pending == PGPU_OK)
@@ -541,6 +547,8 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     }
     if (closest)
         resultBytes = instRows ? 20 : 16;
+    if (streamed)
+        soft(prepareLeafCache(c)); // (the arena, the copy stream, the pinned per-point arrays)
     {
         // the in-place trace of the rays parked at this rank's own points: at most n work items, overflow buffer of its own
         Bvh8TraceArgs probe = ba;
@@ -593,6 +601,8 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         } else {
             HIP_TRY(c, hipMemcpyAsync(gathered.data(), dCounts, 8, hipMemcpyDeviceToHost, stream));
         }
+        if (streamed && pending == PGPU_OK && c->leafHostBuf) // (the per-point counts of the binned list: they cut it into launch groups)
+            HIP_TRY(c, hipMemcpyAsync(c->leafHostBuf, dLeafCount, nl * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(c, hipStreamSynchronize(stream));
         uint64_t total = 0;
         for (uint32_t r = 0; r < world; ++r) {
@@ -621,7 +631,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
         // Rays parked at this rank's own batching points: traced in place from the binned list (the kernel skips the work items
         // whose batching point has no BVH here -- those travel as records). With peers, on a second stream: it touches other rays'
         // results than the records and their merge do, so it runs next to the exchange and the trace of the received records.
-        const bool fork = world > 1 && c->auxStream && c->auxFork && c->auxJoin && (sendTotal || recvTotal);
+        const bool fork = world > 1 && !streamed && c->auxStream && c->auxFork && c->auxJoin && (sendTotal || recvTotal);
         hipStream_t localStream = fork ? c->auxStream : stream;
         bool forked = false;
         if (parked) {
@@ -637,7 +647,24 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
             ba.ray_aos = dRayAos;
             ba.cursor = cursorLocal;
             uint32_t blocks = 1;
-            if (softHip(hipMemsetAsync(cursorLocal, 0, 256, localStream), "hipMemsetAsync") && soft(planBvh8Launch(c, deepest, parked, ba, &blocks, &c->spillB)))
+            if (streamed) {
+                // this rank's points that have rays, up and down alternately (what the last round brought in last is used first)
+                const uint32_t* const hCount = c->leafHostBuf;
+                hLeafStart.resize(nl);
+                visitOrder.clear();
+                uint32_t run = 0;
+                for (size_t l = 0; l < nl; ++l) {
+                    hLeafStart[l] = run;
+                    run += hCount[l];
+                    if (hCount[l] != 0u && c->leafOwnerHost[l] == rank)
+                        visitOrder.push_back(uint32_t(l));
+                }
+                if (rounds % 2 == 0)
+                    std::reverse(visitOrder.begin(), visitOrder.end());
+                ba.work_bvh = dWorkBvh;
+                ba.work_tag = dWorkLeaf;
+                soft(traceLeafGroups(c, ba, kind, tri_mode, deepest, visitOrder, hLeafStart.data(), hCount, cursorLocal, &c->spillB, stream));
+            } else if (softHip(hipMemsetAsync(cursorLocal, 0, 256, localStream), "hipMemsetAsync") && soft(planBvh8Launch(c, deepest, parked, ba, &blocks, &c->spillB)))
                 softHip(launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, localStream), "bottom-level trace");
             if (forked)
                 softHip(hipEventRecord(c->auxJoin, c->auxStream), "hipEventRecord");
@@ -692,7 +719,10 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     HIP_TRY(c, hipMemcpyAsync(cnt, c->topCounters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
     HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
+    const uint64_t leafLoads = c->counters.leaf_loads, streamedBytes = c->counters.streamed_bytes;
     c->counters = pgpu_counters {};
+    c->counters.leaf_loads = leafLoads;
+    c->counters.streamed_bytes = streamedBytes;
     c->counters.svdag_tests = cnt[0];
     c->counters.svdag_culled = cnt[1];
     c->counters.leaf_visits = leafVisits;

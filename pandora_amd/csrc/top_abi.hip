@@ -209,6 +209,68 @@ int commitLeafGroup(pgpu_ctx* c, const LeafGroupPlan& plan, hipStream_t stream)
 
 } // namespace
 
+namespace pandora_hip {
+
+int prepareLeafCache(pgpu_ctx* c) { return ensureLeafCache(c); }
+
+// Bottom-level traversal of a work list that is sorted by batching point, through BVHs that may be staged in host memory: the
+// points of `visitOrder` (ascending or descending slots) whose images fit the HBM cache together form one launch over the
+// contiguous stretch of the list they span; the copies of a group run on the copy stream, behind the last launch that read the
+// space they overwrite and ahead of the launch that needs them. Work items of points that are not in the cache (not in
+// visitOrder, evicted) are dropped by the kernel: their table entry is null. `ba`: the launch arguments with work_ray / work_bvh /
+// work_tag at the list's start.
+int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& visitOrder, const uint32_t* leafStart,
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream)
+{
+    const uint32_t* const listRay = ba.work_ray;
+    const uint32_t* const listBvh = ba.work_bvh;
+    const uint32_t* const listTag = ba.work_tag;
+    ba.cursor = cursor;
+    size_t at = 0;
+    while (at < visitOrder.size()) {
+        const uint64_t group = ++c->groupClock;
+        LeafGroupPlan plan;
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        size_t members = 0;
+        for (; at < visitOrder.size(); ++at, ++members) {
+            const uint32_t l = visitOrder[at];
+            const uint32_t id = c->topLeavesHost[l].bvh;
+            if (id < c->staged.size() && c->staged[id].host && !ringPlace(c, id, group, plan))
+                break; // the cache is full of BVHs this launch needs: launch, then go on
+            lo = std::min(lo, leafStart[l]);
+            hi = std::max(hi, leafStart[l] + leafCount[l]);
+        }
+        if (members == 0)
+            return fail(c, PGPU_ERR_INVALID, "leaf cache: no room for a single BVH (internal)");
+        int rc = commitLeafGroup(c, plan, stream);
+        if (rc != PGPU_OK)
+            return rc;
+        HIP_TRY(c, hipMemsetAsync(cursor, 0, 256, stream));
+        ba.work_ray = listRay + lo;
+        ba.work_bvh = listBvh + lo;
+        ba.work_tag = listTag + lo;
+        ba.n_work = hi - lo;
+        uint32_t blocks = 1;
+        rc = planBvh8Launch(c, deepest, hi - lo, ba, &blocks, spill);
+        if (rc != PGPU_OK)
+            return rc;
+        {
+            const TraceRange r_("round: bottom level, one group of cached batching points");
+            HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+        }
+        if (!plan.touched.empty()) {
+            const size_t ev = c->launchEventNext++ % c->launchEvents.size();
+            HIP_TRY(c, hipEventRecord(c->launchEvents[ev], stream));
+            for (uint32_t id : plan.touched)
+                if (c->staged[id].resident)
+                    c->staged[id].lastLaunch = int(ev);
+        }
+    }
+    return PGPU_OK;
+}
+
+} // namespace pandora_hip
+
 // one record per batching point with its DAG's descriptor inlined (LeafDagDev); needs the leaves, and the DAGs they name
 static int rebuildLeafDags(pgpu_ctx* c)
 {
@@ -946,46 +1008,12 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             }
             if (rounds % 2 == 0) // (`rounds` was incremented above: the first round walks upwards)
                 std::reverse(visitOrder.begin(), visitOrder.end());
-            size_t at = 0;
-            while (at < visitOrder.size()) {
-                const uint64_t group = ++c->groupClock;
-                LeafGroupPlan plan;
-                uint32_t lo = 0xFFFFFFFFu, hi = 0;
-                size_t members = 0;
-                for (; at < visitOrder.size(); ++at, ++members) {
-                    const uint32_t l = visitOrder[at];
-                    const uint32_t id = c->topLeavesHost[l].bvh;
-                    if (id < c->staged.size() && c->staged[id].host && !ringPlace(c, id, group, plan))
-                        break; // the cache is full of BVHs this launch needs: launch, then go on
-                    lo = std::min(lo, hLeafStart[l]);
-                    hi = std::max(hi, hLeafStart[l] + hLeafCount[l]);
-                }
-                if (members == 0)
-                    return fail(c, PGPU_ERR_INVALID, "leaf cache: no room for a single BVH (internal)");
-                rc = commitLeafGroup(c, plan, stream);
-                if (rc != PGPU_OK)
-                    return rc;
-                HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
-                ba.work_ray = workRayAll + lo;
-                ba.work_bvh = dWorkBvh + lo;
-                ba.work_tag = dWorkLeaf + lo;
-                ba.n_work = hi - lo;
-                uint32_t blocks = 1;
-                rc = planBvh8Launch(c, deepest, hi - lo, ba, &blocks);
-                if (rc != PGPU_OK)
-                    return rc;
-                {
-                    const TraceRange r_("round: bottom level, one group of cached batching points");
-                    HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
-                }
-                if (!plan.touched.empty()) {
-                    const size_t ev = c->launchEventNext++ % c->launchEvents.size();
-                    HIP_TRY(c, hipEventRecord(c->launchEvents[ev], stream));
-                    for (uint32_t id : plan.touched)
-                        if (c->staged[id].resident)
-                            c->staged[id].lastLaunch = int(ev);
-                }
-            }
+            ba.work_ray = workRayAll;
+            ba.work_bvh = dWorkBvh;
+            ba.work_tag = dWorkLeaf;
+            rc = traceLeafGroups(c, ba, kind, tri_mode, deepest, visitOrder, hLeafStart.data(), hLeafCount.data(), c->cursor, nullptr, stream);
+            if (rc != PGPU_OK)
+                return rc;
             ba.work_bvh = dWorkBvh;
             ba.work_tag = dWorkLeaf;
             if (nextHeld) {

@@ -24,8 +24,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda", 0)
-        if mode == 3:
-            instanced_landscape(out_dir, kind, rank, world, dev)
+        if mode in (3, 6):  # 6: every rank's batching points staged in host memory, streamed through a cache of a fifth of their bytes
+            instanced_landscape(out_dir, kind, rank, world, dev, streamed=(mode == 6))
             return
         homed = False
         if mode in (4, 5):  # a city of ~0.35 M triangles in ~60 batching points, every rank building only its own (as bench.py does)
@@ -121,18 +121,27 @@ def landscape_scene():
     return pa.accel.build_instanced_two_level(terrain.pos, terrain.idx, [(p.pos, p.idx) for p in protos], proto, mats, 1500, svdag_res=32)
 
 
-def instanced_landscape(out_dir, kind, rank, world, dev):
+def instanced_landscape(out_dir, kind, rank, world, dev, streamed=False):
     """Batching points (terrain triangles + tree instances) alternate between the ranks; every rank holds all prototypes. A ray
     that parks at the other rank's point travels there, may hit a tree through its instance, and the instance id comes back."""
     tl = landscape_scene()
     owner = (np.arange(tl.n_leaves) % world).astype(np.uint32)  # per leaf slot
     ctx = pa.accel.Context(0)
-    tl.upload(ctx, resident=(owner == rank))
+    tl.upload(ctx, streamed=streamed, resident=(owner == rank))
+    if streamed:
+        order = np.asarray(tl.top.leaf_order, np.int64)
+        image = [tl.bvhs[g].n_nodes * 256 + (tl.bvhs[g].leaf_idx.size + 1) * 48 + 64 * tl.group_insts[g].size + 1024 for s, g in enumerate(order) if owner[s] == rank]
+        ctx.set_leaf_cache(max(2 * max(image), sum(image) // 5))
     rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
     d_rays = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)
     sharded.comm_init(ctx, dev, host_staged=True)
     ctx.set_leaf_owners(owner)
     st, cnt = ctx.trace_sharded(d_rays, kind=kind)
+    if streamed:
+        assert cnt["leaf_loads"] > len(image) and cnt["streamed_bytes"] > sum(image), "the cache holds a fifth of this rank's images: they must be loaded more than once"
+        st2, cnt2 = ctx.trace_sharded(d_rays, kind=kind)  # again, from a warm cache: same results
+        for k in st:
+            assert torch.equal(st[k], st2[k]), k
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), routed=cnt["records_routed"], rounds=cnt["rounds"], leaf_visits=cnt["leaf_visits"],
              svdag_tests=cnt["svdag_tests"], svdag_culled=cnt["svdag_culled"], **{k: v.cpu().numpy() for k, v in st.items()})
     ctx.close()

@@ -249,11 +249,14 @@ def test_four_processes_sharded_city(mode):
     assert sum(int(p["svdag_culled"]) for p in parts) == wcnt["svdag_culled"]
 
 
+@pytest.mark.parametrize("mode", [3, 6], ids=["resident", "staged_cache_a_fifth"])
 @pytest.mark.parametrize("kind", [pa.capi.CLOSEST, pa.capi.ANY], ids=["closest", "any"])
-def test_two_processes_sharded_instanced_landscape(kind):
+def test_two_processes_sharded_instanced_landscape(kind, mode):
     """Instanced leaves + batching points sharded over two ranks (pgpu_trace_sharded): the instancing BVHs live on their owners,
     the prototypes on both; results -- the instance a hit went through included, which travels back as a fifth value of the
-    result row -- equal one context's pgpu_trace, which tests/test_gpu_instances.py checks against the oracle."""
+    result row -- equal one context's pgpu_trace, which tests/test_gpu_instances.py checks against the oracle.
+    staged: BASELINE configs[4] as stated -- sharded AND streamed: every rank keeps its batching points in pinned host memory and
+    streams them through an HBM cache of a fifth of their bytes, for the rays parked there in place and for the records it receives."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
@@ -279,7 +282,7 @@ def test_two_processes_sharded_instanced_landscape(kind):
         procs = []
         for r in range(2):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(kind), "3"], env=env,
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "sharded_gpu_worker.py"), d, str(kind), str(mode)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
         assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
