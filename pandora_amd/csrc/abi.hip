@@ -285,6 +285,8 @@ int pgpu_init(int device_id, pgpu_ctx** out)
         return PGPU_ERR_HIP;
     }
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = std::getenv("PANDORA_LEAF_DRAIN")) // (tuning knob of the streamed loop's queue policy, top_abi.hip; results do not depend on it)
+        c->leafDrainRatio = float(std::atof(e));
     if (initStaticScratch(c) != PGPU_OK) {
         pgpu_shutdown(c);
         return PGPU_ERR_HIP;
@@ -338,7 +340,7 @@ void pgpu_shutdown(pgpu_ctx* c)
     for (hipEvent_t e : { c->auxFork, c->auxJoin })
         if (e)
             (void)hipEventDestroy(e);
-    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv, &c->spillB })
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv, &c->spillB, &c->tableView })
         if (b->ptr)
             (void)hipFree(b->ptr);
     if (c->ev0)

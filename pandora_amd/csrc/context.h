@@ -102,12 +102,16 @@ struct pgpu_ctx {
     std::deque<uint32_t> ring;
     uint64_t groupClock = 0;
     uint32_t leafHoldBytesPerRay = 256; // pgpu_set_leaf_hold: an image that is not in the cache is loaded once its point holds a ray per this many bytes (0: always)
+    float leafDrainRatio = 4.0f; // waiting queues are flushed as well once they hold more than this many times the rays that still move (PANDORA_LEAF_DRAIN)
     int leafCopyMode = 0;   // pgpu_set_leaf_copy: 0 = one gather kernel per launch group reads the pinned images, 1 = one hipMemcpyAsync per image
     void* copyTableHost = nullptr; // pinned: the gather kernel's segments and the BVH-table entries that changed, one run per launch group
     void* copyTableDev = nullptr;
     size_t copyTableCap = 0, copyTableNext = 0; // in 64-byte records
     uint32_t* leafHostBuf = nullptr; // pinned: per-point counts read back every round, and the two per-point arrays the host sends (3 n_leaves + 64 words)
     size_t leafHostCap = 0;
+    // the launches that trace only what their group brought in (pgpu_trace's second pass of a round, see top_abi.hip) use a view
+    // of the BVH table: [view table][per id: named by a batching point?][per id: the group it arrived with], bvhTableCap entries each
+    DeviceBuffer tableView;
     hipStream_t copyStream = nullptr;
     hipEvent_t copyDone = nullptr;
     std::vector<pandora_hip::SvdagDev> dagsHost; // host copy of the descriptors (for the per-point records, LeafDagDev)
@@ -156,8 +160,9 @@ int initStaticScratch(pgpu_ctx* c); // noalloc.hip
 // top_abi.hip: the HBM cache of staged BVHs (built on first use), and the bottom level over a work list sorted by batching point
 // when some BVHs are staged -- launch groups by what fits the cache together (see there)
 int prepareLeafCache(pgpu_ctx* c);
+// (arrivalsOnly: every launch sees, of the BVHs batching points name, only the images its own group brought in)
 int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& visitOrder, const uint32_t* leafStart,
-    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream);
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream, bool arrivalsOnly = false);
 // route_abi.hip. instRows: closest-hit result rows have five values (the instance of the hit last), see launchPackResults
 // (cursor / spill: for a launch that runs next to another bottom-level launch of the same context; default = the context's)
 int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows = false,

@@ -249,12 +249,19 @@ struct LeafCopySeg {
 struct LeafTableFix {
     Bvh8Dev entry;
     uint32_t id;
+    uint32_t group; // the launch group (its low 32 bits) an arriving image belongs to; 0 for an image that leaves
 };
 static_assert(sizeof(LeafCopySeg) == 64 && sizeof(LeafTableFix) <= 64, "one 64-byte record each");
 hipError_t launchLeafGather(const LeafCopySeg* segs, uint32_t nSegs, uint32_t nChunks, uint32_t blocks, hipStream_t stream);
 hipError_t launchAddCounts(uint32_t* count, const uint32_t* add, uint32_t n, hipStream_t stream);
 hipError_t launchSplitByLeaf(const uint32_t* workRay, const uint32_t* leafStart, const uint32_t* leafCount, const uint32_t* dst, uint32_t nLeaves,
     uint32_t* nextActive, uint32_t* heldRay, uint32_t* heldLeaf, uint32_t blocks, hipStream_t stream);
-hipError_t launchLeafTableFix(const unsigned char* fixes64, uint32_t nFixes, Bvh8Dev* table, hipStream_t stream);
+// (arrivalGroup, optional: per BVH id the launch group it arrived with, see launchLeafTableView)
+hipError_t launchLeafTableFix(const unsigned char* fixes64, uint32_t nFixes, Bvh8Dev* table, hipStream_t stream, uint32_t* arrivalGroup = nullptr);
+// view[i] = table[i], except that a BVH a batching point names (leafFlag[i] != 0) is there only if it arrived with launch group
+// `group`: the table a launch uses that must trace the images its group brought in and nothing that an earlier launch of the round
+// has traced already (prototypes of instances, which no batching point names, stay visible)
+hipError_t launchLeafTableView(const Bvh8Dev* table, const uint32_t* leafFlag, const uint32_t* arrivalGroup, uint32_t group, Bvh8Dev* view, uint32_t n,
+    hipStream_t stream);
 
 } // namespace pandora_hip

@@ -49,12 +49,29 @@ __global__ __launch_bounds__(256) void leafGatherKernel(const LeafCopySeg* __res
     }
 }
 
-__global__ void leafTableFixKernel(const unsigned char* __restrict__ fixes64, uint32_t nFixes, Bvh8Dev* __restrict__ table)
+__global__ void leafTableFixKernel(const unsigned char* __restrict__ fixes64, uint32_t nFixes, Bvh8Dev* __restrict__ table, uint32_t* __restrict__ arrivalGroup)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nFixes) {
         const LeafTableFix f = *reinterpret_cast<const LeafTableFix*>(fixes64 + size_t(i) * 64u);
         table[f.id] = f.entry;
+        if (arrivalGroup)
+            arrivalGroup[f.id] = f.group;
+    }
+}
+
+__global__ void leafTableViewKernel(const Bvh8Dev* __restrict__ table, const uint32_t* __restrict__ leafFlag, const uint32_t* __restrict__ arrivalGroup,
+    uint32_t group, Bvh8Dev* __restrict__ view, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        Bvh8Dev e = table[i];
+        if (leafFlag[i] != 0u && arrivalGroup[i] != group) {
+            e.nodes = nullptr;
+            e.tris = nullptr;
+            e.inst = nullptr;
+        }
+        view[i] = e;
     }
 }
 
@@ -113,11 +130,20 @@ hipError_t launchLeafGather(const LeafCopySeg* segs, uint32_t nSegs, uint32_t nC
     return hipGetLastError();
 }
 
-hipError_t launchLeafTableFix(const unsigned char* fixes64, uint32_t nFixes, Bvh8Dev* table, hipStream_t stream)
+hipError_t launchLeafTableFix(const unsigned char* fixes64, uint32_t nFixes, Bvh8Dev* table, hipStream_t stream, uint32_t* arrivalGroup)
 {
     if (nFixes == 0u)
         return hipSuccess;
-    hipLaunchKernelGGL(leafTableFixKernel, dim3((nFixes + 63u) / 64u), dim3(64), 0, stream, fixes64, nFixes, table);
+    hipLaunchKernelGGL(leafTableFixKernel, dim3((nFixes + 63u) / 64u), dim3(64), 0, stream, fixes64, nFixes, table, arrivalGroup);
+    return hipGetLastError();
+}
+
+hipError_t launchLeafTableView(const Bvh8Dev* table, const uint32_t* leafFlag, const uint32_t* arrivalGroup, uint32_t group, Bvh8Dev* view, uint32_t n,
+    hipStream_t stream)
+{
+    if (n == 0u)
+        return hipSuccess;
+    hipLaunchKernelGGL(leafTableViewKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, table, leafFlag, arrivalGroup, group, view, n);
     return hipGetLastError();
 }
 

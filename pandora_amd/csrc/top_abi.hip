@@ -8,6 +8,8 @@
 #include <cmath>
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace pandora_hip;
 
@@ -153,7 +155,7 @@ bool ringPlace(pgpu_ctx* c, uint32_t id, uint64_t group, LeafGroupPlan& plan)
 
 // Queues the copies of a launch group on the copy stream and the changes of the device BVH table on the compute stream (behind
 // the copies, and behind the previous launch, which may still read the entries of the images that leave).
-int commitLeafGroup(pgpu_ctx* c, const LeafGroupPlan& plan, hipStream_t stream)
+int commitLeafGroup(pgpu_ctx* c, const LeafGroupPlan& plan, hipStream_t stream, uint64_t group)
 {
     if (plan.arrived.empty() && plan.evicted.empty())
         return PGPU_OK;
@@ -190,6 +192,7 @@ int commitLeafGroup(pgpu_ctx* c, const LeafGroupPlan& plan, hipStream_t stream)
         LeafTableFix fix {};
         fix.entry = c->bvhs[id];
         fix.id = id;
+        fix.group = c->staged[id].resident ? uint32_t(group) : 0u;
         std::memcpy(host + (nSeg + f++) * 64, &fix, sizeof(fix));
     };
     for (uint32_t id : plan.evicted)
@@ -203,7 +206,35 @@ int commitLeafGroup(pgpu_ctx* c, const LeafGroupPlan& plan, hipStream_t stream)
         HIP_TRY(c, launchLeafGather(reinterpret_cast<const LeafCopySeg*>(dev), uint32_t(nSeg), uint32_t(chunks), uint32_t(c->numCUs) * 4u, c->copyStream));
     HIP_TRY(c, hipEventRecord(c->copyDone, c->copyStream));
     HIP_TRY(c, hipStreamWaitEvent(stream, c->copyDone, 0));
-    HIP_TRY(c, launchLeafTableFix(dev + nSeg * 64, uint32_t(f), c->bvhTable, stream));
+    uint32_t* const arrivalGroup = c->tableView.ptr ? reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->tableView.ptr) + c->bvhTableCap * (sizeof(Bvh8Dev) + 4)) : nullptr;
+    HIP_TRY(c, launchLeafTableFix(dev + nSeg * 64, uint32_t(f), c->bvhTable, stream, arrivalGroup));
+    return PGPU_OK;
+}
+
+// The view of the BVH table for launches that trace only their own group's arrivals (kernels.h launchLeafTableView): the view
+// itself, which ids a batching point names, and the group every id arrived with (rebuilt whenever the cache is: nothing is
+// resident then).
+int prepareTableView(pgpu_ctx* c)
+{
+    const size_t cap = c->bvhTableCap;
+    const size_t bytes = cap * (sizeof(Bvh8Dev) + 8);
+    if (c->tableView.bytes >= bytes && c->tableView.ptr)
+        return PGPU_OK;
+    int rc = ensure(c, c->tableView, bytes);
+    if (rc != PGPU_OK)
+        return rc;
+    return PGPU_OK;
+}
+int fillTableView(pgpu_ctx* c, hipStream_t stream)
+{
+    const size_t cap = c->bvhTableCap;
+    std::vector<uint32_t> flag(2 * cap, 0u); // [named by a batching point?][arrival group = 0: none]
+    for (const TopLeafDev& l : c->topLeavesHost)
+        if (l.bvh < cap)
+            flag[l.bvh] = 1u;
+    // (images that are resident from an earlier trace keep group 0: no arrivals-only launch of this trace brought them in)
+    HIP_TRY(c, hipMemcpyAsync(static_cast<unsigned char*>(c->tableView.ptr) + cap * sizeof(Bvh8Dev), flag.data(), flag.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream)); // (pageable source)
     return PGPU_OK;
 }
 
@@ -220,14 +251,18 @@ int prepareLeafCache(pgpu_ctx* c) { return ensureLeafCache(c); }
 // visitOrder, evicted) are dropped by the kernel: their table entry is null. `ba`: the launch arguments with work_ray / work_bvh /
 // work_tag at the list's start.
 int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& visitOrder, const uint32_t* leafStart,
-    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream)
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream, bool arrivalsOnly)
 {
+    if (arrivalsOnly && !c->tableView.ptr)
+        return fail(c, PGPU_ERR_INVALID, "leaf cache: no table view (internal)");
     const uint32_t* const listRay = ba.work_ray;
     const uint32_t* const listBvh = ba.work_bvh;
     const uint32_t* const listTag = ba.work_tag;
     ba.cursor = cursor;
     size_t at = 0;
     while (at < visitOrder.size()) {
+        if (uint32_t(c->groupClock + 1) == 0u)
+            ++c->groupClock; // (the low 32 bits name the group on the device; 0 means "none")
         const uint64_t group = ++c->groupClock;
         LeafGroupPlan plan;
         uint32_t lo = 0xFFFFFFFFu, hi = 0;
@@ -242,9 +277,15 @@ int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint3
         }
         if (members == 0)
             return fail(c, PGPU_ERR_INVALID, "leaf cache: no room for a single BVH (internal)");
-        int rc = commitLeafGroup(c, plan, stream);
+        int rc = commitLeafGroup(c, plan, stream, group);
         if (rc != PGPU_OK)
             return rc;
+        if (arrivalsOnly) {
+            Bvh8Dev* const view = static_cast<Bvh8Dev*>(c->tableView.ptr);
+            const uint32_t* const leafFlag = reinterpret_cast<const uint32_t*>(static_cast<unsigned char*>(c->tableView.ptr) + c->bvhTableCap * sizeof(Bvh8Dev));
+            HIP_TRY(c, launchLeafTableView(c->bvhTable, leafFlag, leafFlag + c->bvhTableCap, uint32_t(group), view, uint32_t(c->bvhs.size()), stream));
+            ba.bvhs = view;
+        }
         HIP_TRY(c, hipMemsetAsync(cursor, 0, 256, stream));
         ba.work_ray = listRay + lo;
         ba.work_bvh = listBvh + lo;
@@ -583,8 +624,9 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     }
     // streamed leaves: rays held at batching points whose image is not loaded yet (ray, point; double buffered), the list of the
     // rays that go on, and two per-point arrays the host fills every round
-    size_t oHeld = 0, oNextActive = 0, oHeldCount = 0, oSplitDst = 0;
+    size_t oHeld = 0, oNextActive = 0, oHeldCount = 0, oSplitDst = 0, oWorkBvhEarly = 0;
     if (c->nStaged > 0) {
+        oWorkBvhEarly = carve(n * 4);
         oHeld = carve(n * 4 * 4);
         oNextActive = carve(n * 4);
         oHeldCount = carve(2 * nl * 4); // held counts, then the split destinations (sent together)
@@ -716,11 +758,12 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     if (rc != PGPU_OK)
         return rc;
     std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder;
-    std::vector<uint8_t> traced;
+    std::vector<uint8_t> traced, inCache;
     uint32_t* dHeldRay[2] = { nullptr, nullptr };
     uint32_t* dHeldLeaf[2] = { nullptr, nullptr };
-    uint32_t *dNextActive = nullptr, *dHeldCount = nullptr, *dSplitDst = nullptr;
+    uint32_t *dNextActive = nullptr, *dHeldCount = nullptr, *dSplitDst = nullptr, *dWorkBvhEarly = nullptr;
     if (streaming) {
+        dWorkBvhEarly = reinterpret_cast<uint32_t*>(wb + oWorkBvhEarly);
         uint32_t* h = reinterpret_cast<uint32_t*>(wb + oHeld);
         dHeldRay[0] = h, dHeldLeaf[0] = h + n, dHeldRay[1] = h + 2 * n, dHeldLeaf[1] = h + 3 * n;
         dNextActive = reinterpret_cast<uint32_t*>(wb + oNextActive);
@@ -765,6 +808,19 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     // quad kernel, which is bound by instruction issue, the extra scalar state cost 3 % on the single-level benchmark. A forced
     // quad layout therefore runs round by round.)
     const bool pairLists = c->hasInstances || c->lanesPerRay == 0u || c->lanesPerRay == 2u; // (instanced scenes: the quad kernel's instanced variant does the same)
+    // streamed scenes: a round's bottom level runs in two passes (see the loop below) when the kernel can take its list length from
+    // device memory; pgpu_set_round_lookahead(ctx, 0) restores the single pass behind the host's decision
+    const bool earlyPass = streaming && pairLists && c->roundLookahead;
+    if (earlyPass) {
+        for (hipEvent_t& e : c->roundEv)
+            if (!e)
+                HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        rc = prepareTableView(c);
+        if (rc == PGPU_OK)
+            rc = fillTableView(c, stream);
+        if (rc != PGPU_OK)
+            return rc;
+    }
     if (!streaming && c->deferMin == 0u && c->roundLookahead && pairLists) {
         if (c->roundCountsCap < nl + 8) {
             if (c->roundCounts)
@@ -899,11 +955,48 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             HIP_TRY(c, launchBinByLeaf(dHeldRay[heldBuf], dHeldLeaf[heldBuf], nHeld, uint32_t(nl), dLeafStart, dLeafFill, c->top.leaves, workRayOut, dWorkBvh,
                            dWorkLeaf, std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nHeld + 255u) / 256u)), stream));
         uint32_t parked = 0;
+        const bool firstPassRan = streaming && earlyPass && nActive > 0;
+        int firstPassEvent = -1;
         if (streaming) {
             // one read per round: the per-point counts (pinned); the total and the starts follow from them
             uint32_t* const pc = c->leafHostBuf;
             HIP_TRY(c, hipMemcpyAsync(pc, dLeafCount, nl * 4, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipStreamSynchronize(stream));
+            if (earlyPass) {
+                HIP_TRY(c, hipEventRecord(c->roundEv[0], stream)); // (the host waits for the counts, not for what is queued behind them)
+                if (nActive > 0) {
+                    // First pass of the round, queued BEFORE the host looks at anything: the rays the episode has just parked, in
+                    // the order of its list, through the BVH table as it stands -- batching points whose image is in the cache (or
+                    // was never staged) are traced, the work items of the others are dropped by the kernel (null table entry) and
+                    // are traced by the second pass, out of the binned list, once their image has come in. (Rays held from earlier
+                    // rounds wait at points that are not in the cache: they are not in this pass.) While it runs the host reads the
+                    // counts, decides what to load, and the copies go out: the round's loads overlap its own traversal instead of
+                    // standing in front of it. The bottom level does not need its list sorted by point.
+                    const TraceRange r_("round: bottom level, first pass (batching points already in the cache)");
+                    HIP_TRY(c, launchLeafToBvh(dParkedLeaf, c->top.leaves, uint32_t(nl), dWorkBvhEarly, nActive,
+                                   std::max(1u, std::min(uint32_t(c->numCUs) * 8u, (nActive + 255u) / 256u)), stream));
+                    HIP_TRY(c, hipMemsetAsync(c->cursor, 0, 256, stream));
+                    Bvh8TraceArgs ea = ba;
+                    ea.bvhs = c->bvhTable;
+                    ea.work_ray = active;
+                    ea.work_bvh = dWorkBvhEarly;
+                    ea.work_tag = dParkedLeaf;
+                    ea.n_work = nActive;
+                    ea.n_work_dev = nullptr;
+                    ea.ray_aos = (c->hasInstances || active != nullptr) ? dRayAos : nullptr; // (identity list of a plain scene: the quad kernel, caller's arrays)
+                    ea.chunk = c->chunk;
+                    uint32_t blocks = 1;
+                    rc = planBvh8Launch(c, deepest, nActive, ea, &blocks);
+                    if (rc != PGPU_OK)
+                        return rc;
+                    HIP_TRY(c, launchBvh8Trace(ea, kind, tri_mode, c->stats, blocks, stream));
+                    // (which images it reads is known once the counts are here: they are marked below, before anything is placed)
+                    firstPassEvent = int(c->launchEventNext++ % c->launchEvents.size());
+                    HIP_TRY(c, hipEventRecord(c->launchEvents[size_t(firstPassEvent)], stream));
+                }
+                HIP_TRY(c, hipEventSynchronize(c->roundEv[0]));
+            } else {
+                HIP_TRY(c, hipStreamSynchronize(stream));
+            }
             hLeafCount.assign(pc, pc + nl);
             hLeafStart.resize(nl);
             for (size_t l = 0; l < nl; ++l) {
@@ -947,10 +1040,14 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 return (id < c->staged.size() && c->staged[id].host) ? &c->staged[id] : nullptr;
             };
             size_t nTraced = 0, nWaiting = 0;
+            inCache.assign(nl, 0); // points the first pass has traced already (with earlyPass): nothing to load, nothing to launch
             for (size_t l = 0; l < nl; ++l) {
                 if (hLeafCount[l] == 0)
                     continue;
                 const StagedBvh* im = stagedImage(l);
+                inCache[l] = firstPassRan && (!im || im->resident);
+                if (inCache[l] && im) // the first pass reads this image: it is not overwritten before that launch is done
+                    c->staged[c->topLeavesHost[l].bvh].lastLaunch = firstPassEvent;
                 if (!mayHold || !im || im->resident || uint64_t(hLeafCount[l]) * c->leafHoldBytesPerRay >= im->imageBytes()) {
                     traced[l] = 1;
                     ++nTraced;
@@ -958,21 +1055,41 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                     ++nWaiting;
                 }
             }
-            if (nTraced == 0) {
+            // Waiting only pays while rays can still arrive: the rays that go on this round (at most that many join the queues
+            // next round) against the rays that wait. Once more rays wait than move -- or nothing moves at all -- the queues will
+            // not fill any further: the waiting points with the most rays per byte are flushed too, up to one cache-full of
+            // images per round in all. (Without this the tail of a trace is a string of rounds in which a few rays bounce
+            // between cached points while tens of thousands sit in queues that never reach their threshold: 89 rounds, against 47
+            // with a ratio of 4 on the benchmark landscape -- 1 halves the rounds again but loads a quarter more bytes and is slower,
+            // profiles/r3_landscape_drain_sweep.txt.)
+            uint64_t raysOn = 0, raysWaiting = 0;
+            size_t loadBytes = 0;
+            for (size_t l = 0; l < nl; ++l) {
+                if (hLeafCount[l] == 0)
+                    continue;
+                if (traced[l]) {
+                    raysOn += hLeafCount[l];
+                    const StagedBvh* im = stagedImage(l);
+                    if (im && !im->resident)
+                        loadBytes += alignUp(im->imageBytes());
+                } else {
+                    raysWaiting += hLeafCount[l];
+                }
+            }
+            if (nWaiting && (nTraced == 0 || double(raysWaiting) > c->leafDrainRatio * double(raysOn))) {
                 visitOrder.clear();
                 for (size_t l = 0; l < nl; ++l)
-                    if (hLeafCount[l] != 0)
+                    if (hLeafCount[l] != 0 && !traced[l])
                         visitOrder.push_back(uint32_t(l));
                 std::sort(visitOrder.begin(), visitOrder.end(), [&](uint32_t x, uint32_t y) {
                     const double rx = double(hLeafCount[x]) / double(stagedImage(x)->imageBytes()), ry = double(hLeafCount[y]) / double(stagedImage(y)->imageBytes());
                     return rx > ry || (rx == ry && x < y);
                 });
-                size_t bytes = 0;
                 for (uint32_t l : visitOrder) {
                     const size_t b = alignUp(stagedImage(l)->imageBytes());
-                    if (nTraced && bytes + b > c->cacheBytes)
+                    if (nTraced && loadBytes + b > c->cacheBytes)
                         break;
-                    bytes += b;
+                    loadBytes += b;
                     traced[l] = 1;
                     ++nTraced;
                     --nWaiting;
@@ -982,10 +1099,14 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             uint64_t tracedRays = 0;
             for (size_t l = 0; l < nl; ++l)
                 if (traced[l]) {
-                    visitOrder.push_back(uint32_t(l));
+                    if (!inCache[l])
+                        visitOrder.push_back(uint32_t(l)); // second pass: the points whose image has to come in first
                     tracedRays += hLeafCount[l];
                 }
             leafVisits += tracedRays;
+            if (std::getenv("PANDORA_TRACE_ROUNDS"))
+                std::fprintf(stderr, "round %llu: parked %u (active %u held %u) traced rays %llu, points traced %zu (second pass %zu) waiting %zu\n",
+                    (unsigned long long)rounds, parked, nActive, nHeld, (unsigned long long)tracedRays, nTraced, visitOrder.size(), nWaiting);
             if (nWaiting) { // split the binned list: the traced points' rays go on, the others wait (one small kernel; skipped when nothing waits)
                 uint32_t* const hHeldCount = c->leafHostBuf + nl; // (pinned; read by the copies queued at the end of the round)
                 uint32_t* const hSplitDst = c->leafHostBuf + 2 * nl;
@@ -1011,9 +1132,11 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
             ba.work_ray = workRayAll;
             ba.work_bvh = dWorkBvh;
             ba.work_tag = dWorkLeaf;
-            rc = traceLeafGroups(c, ba, kind, tri_mode, deepest, visitOrder, hLeafStart.data(), hLeafCount.data(), c->cursor, nullptr, stream);
+            ba.chunk = c->chunk;
+            rc = traceLeafGroups(c, ba, kind, tri_mode, deepest, visitOrder, hLeafStart.data(), hLeafCount.data(), c->cursor, nullptr, stream, firstPassRan);
             if (rc != PGPU_OK)
                 return rc;
+            ba.bvhs = c->bvhTable;
             ba.work_bvh = dWorkBvh;
             ba.work_tag = dWorkLeaf;
             if (nextHeld) {
