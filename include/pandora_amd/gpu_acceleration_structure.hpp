@@ -310,6 +310,53 @@ namespace detail {
 
 } // namespace detail
 
+// What a batch handler gets (GpuAccelerationStructure::setBatchHandlers): a run of rays that were buffered one behind the other --
+// by one thread's intersect() calls or by one intersectBatch() -- with their results as arrays. One std::function call per run
+// (up to 8192 rays) instead of one per ray, and nothing is computed for a ray the handler does not look at: the per-ray handlers
+// are handed a RayHit with the geometric normal of every hit (what the reference's leaf computes for every TENTATIVE hit,
+// offline_bvh_cache.cpp:48-49), which costs three random reads into the mesh per ray; here hit(i) does that on request.
+template <typename State>
+struct RayBatch {
+    size_t n = 0;
+    const Ray* rays = nullptr;      // the n rays as they were handed to intersect(); nullptr for rays that came through intersectBatch
+    const float* soa[8] {};         // ... whose origin / direction / tnear / tfar arrays (n values each) are here instead
+    const State* states = nullptr;  // n ray states
+    // closest hit (null for an any-hit batch): hit distance (a miss keeps the ray's tfar), leaf-object index (PGPU_MISS = miss),
+    // batching point, barycentrics
+    const float* t = nullptr;
+    const uint32_t* obj = nullptr;
+    const uint32_t* leaf = nullptr;
+    const float* u = nullptr;
+    const float* v = nullptr;
+    const uint32_t* occluded = nullptr; // any hit (null for a closest-hit batch): 1 = something lies inside [tnear, tfar]
+    const uint32_t* visits = nullptr;   // Ray::numTopLevelIntersections gained by this trace (two-level scenes), else nullptr
+    std::function<RayHit(const Ray&, uint32_t, uint32_t, float, float)> const* surfaceFn = nullptr;
+
+    bool isHit(size_t i) const { return obj ? obj[i] != PGPU_MISS : occluded[i] != 0u; }
+    Ray ray(size_t i) const // as the per-ray handlers get it: tfar = hit distance (-inf for an occluded shadow ray), visits added
+    {
+        Ray r;
+        if (rays) {
+            r = rays[i];
+        } else {
+            for (int a = 0; a < 3; ++a) {
+                r.origin[a] = soa[a][i];
+                r.direction[a] = soa[3 + a][i];
+            }
+            r.tnear = soa[6][i];
+            r.tfar = soa[7][i];
+        }
+        if (visits)
+            r.numTopLevelIntersections += visits[i];
+        if (obj && obj[i] != PGPU_MISS)
+            r.tfar = t[i];
+        if (occluded && occluded[i])
+            r.tfar = -std::numeric_limits<float>::infinity();
+        return r;
+    }
+    RayHit hit(size_t i) const { return (*surfaceFn)(ray(i), leaf[i], obj[i], u[i], v[i]); } // (closest-hit batches, isHit(i) only)
+};
+
 template <typename HitRayState, typename AnyHitRayState>
 class GpuAccelerationStructure {
 public:
@@ -317,6 +364,8 @@ public:
     using OnMiss = std::function<void(const Ray&, const HitRayState&)>;
     using OnAnyHit = std::function<void(const Ray&, const AnyHitRayState&)>;
     using OnAnyMiss = std::function<void(const Ray&, const AnyHitRayState&)>;
+    using OnClosestBatch = std::function<void(const RayBatch<HitRayState>&)>;
+    using OnAnyBatch = std::function<void(const RayBatch<AnyHitRayState>&)>;
 
     GpuAccelerationStructure(GpuAccelerationStructure&&) noexcept = default;
     GpuAccelerationStructure(const GpuAccelerationStructure&) = delete;
@@ -344,13 +393,31 @@ public:
         b.anyStates.push_back(state);
     }
 
+    // The same for callers that hold their rays as arrays already (a wavefront integrator): n rays as eight arrays and n states, copied
+    // into the calling thread's buffer as they are -- no AoS detour on the way to the GPU, which wants exactly these arrays.
+    void intersectBatch(const pgpu_rays& rays, size_t n, const HitRayState* states) const { local().chunks.emplace_back(new SoaChunk<HitRayState>(rays, n, states)); }
+    void intersectAnyBatch(const pgpu_rays& rays, size_t n, const AnyHitRayState* states) const { local().anyChunks.emplace_back(new SoaChunk<AnyHitRayState>(rays, n, states)); }
+
+    // Results in runs instead of one call per ray (see RayBatch). A kind whose batch handler is set no longer calls its per-ray
+    // handlers; pass an empty function to go back. Call between flushes.
+    void setBatchHandlers(OnClosestBatch closest, OnAnyBatch any)
+    {
+        m->onClosestBatch = std::move(closest);
+        m->onAnyBatch = std::move(any);
+    }
+
     // rays waiting for the next flush() (call it while no thread is inside intersect()/intersectAny())
     size_t pending() const
     {
         std::lock_guard<std::mutex> l(m->registryMutex);
         size_t n = 0;
-        for (auto& kv : m->byThread)
+        for (auto& kv : m->byThread) {
             n += kv.second->rays.size() + kv.second->anyRays.size();
+            for (auto& ch : kv.second->chunks)
+                n += ch->n;
+            for (auto& ch : kv.second->anyChunks)
+                n += ch->n;
+        }
         return n;
     }
 
@@ -364,19 +431,25 @@ public:
             std::lock_guard<std::mutex> l(m->registryMutex);
             for (auto& kv : m->byThread) {
                 ThreadBuf& b = *kv.second;
-                if (b.rays.empty() && b.anyRays.empty())
+                if (b.rays.empty() && b.anyRays.empty() && b.chunks.empty() && b.anyChunks.empty())
                     continue;
                 taken.emplace_back(new ThreadBuf());
                 taken.back()->rays.swap(b.rays);
                 taken.back()->states.swap(b.states);
                 taken.back()->anyRays.swap(b.anyRays);
                 taken.back()->anyStates.swap(b.anyStates);
+                taken.back()->chunks.swap(b.chunks);
+                taken.back()->anyChunks.swap(b.anyChunks);
             }
         }
         Gathered closest, any;
         for (auto& t : taken) {
-            closest.add(t->rays.data(), t->rays.size(), t->states.data(), nullptr);
-            any.add(t->anyRays.data(), t->anyRays.size(), nullptr, t->anyStates.data());
+            closest.add(t->rays.data(), nullptr, t->rays.size(), t->states.data(), nullptr);
+            any.add(t->anyRays.data(), nullptr, t->anyRays.size(), nullptr, t->anyStates.data());
+            for (auto& ch : t->chunks)
+                closest.add(nullptr, ch->data.data(), ch->n, ch->states.data(), nullptr);
+            for (auto& ch : t->anyChunks)
+                any.add(nullptr, ch->data.data(), ch->n, nullptr, ch->states.data());
         }
         const size_t total = closest.total() + any.total();
         if (total == 0)
@@ -424,25 +497,70 @@ public:
 private:
     friend class GpuAccelerationStructureBuilder;
 
+    template <typename State>
+    struct SoaChunk { // one intersectBatch call: the eight arrays one behind the other (n values each) and the states
+        size_t n;
+        std::vector<float> data;
+        std::vector<State> states;
+        SoaChunk(const pgpu_rays& r, size_t count, const State* st)
+            : n(count)
+            , data(8 * count)
+            , states(st, st + count)
+        {
+            const float* const src[8] = { r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.tnear, r.tfar };
+            for (int a = 0; a < 8; ++a)
+                std::memcpy(data.data() + size_t(a) * n, src[a], n * sizeof(float));
+        }
+    };
     struct ThreadBuf {
         std::vector<Ray> rays, anyRays;
         std::vector<HitRayState> states;
         std::vector<AnyHitRayState> anyStates;
+        std::vector<std::unique_ptr<SoaChunk<HitRayState>>> chunks;
+        std::vector<std::unique_ptr<SoaChunk<AnyHitRayState>>> anyChunks;
     };
 
     // the buffered rays of one kind, as a list of per-thread segments addressed by one running index
     struct Gathered {
         struct Seg {
-            const Ray* rays;
+            const Ray* rays;  // AoS rays (intersect), or
+            const float* soa; // eight arrays of n values one behind the other (intersectBatch)
             const HitRayState* states;
             const AnyHitRayState* anyStates;
             size_t first, n;
+            Ray ray(size_t k) const
+            {
+                if (rays)
+                    return rays[k];
+                Ray r;
+                for (int a = 0; a < 3; ++a) {
+                    r.origin[a] = soa[size_t(a) * n + k];
+                    r.direction[a] = soa[size_t(3 + a) * n + k];
+                }
+                r.tnear = soa[6 * n + k];
+                r.tfar = soa[7 * n + k];
+                return r;
+            }
         };
         std::vector<Seg> segs;
-        void add(const Ray* rays, size_t n, const HitRayState* s, const AnyHitRayState* as)
+        void add(const Ray* rays, const float* soa, size_t n, const HitRayState* s, const AnyHitRayState* as)
         {
             if (n)
-                segs.push_back({ rays, s, as, total(), n });
+                segs.push_back({ rays, soa, s, as, total(), n });
+        }
+        // calls f(segment, first index inside the segment, count, running index of the first) for the runs that make up [lo, hi)
+        template <typename F>
+        void eachRun(size_t lo, size_t hi, F&& f) const
+        {
+            if (lo >= hi)
+                return;
+            size_t s = size_t(std::upper_bound(segs.begin(), segs.end(), lo, [](size_t v, const Seg& g) { return v < g.first; }) - segs.begin()) - 1;
+            for (size_t i = lo; i < hi; ++s) {
+                const Seg& g = segs[s];
+                const size_t k = i - g.first, count = std::min(g.n - k, hi - i);
+                f(g, k, count, i);
+                i += count;
+            }
         }
         size_t total() const { return segs.empty() ? 0 : segs.back().first + segs.back().n; }
         // calls f(segment, index inside the segment, running index) for the running indices [lo, hi)
@@ -522,6 +640,9 @@ private:
         OnMiss onMiss;
         OnAnyHit onAnyHit;
         OnAnyMiss onAnyMiss;
+        OnClosestBatch onClosestBatch;
+        OnAnyBatch onAnyBatch;
+        std::function<RayHit(const Ray&, uint32_t, uint32_t, float, float)> surfaceFn; // RayBatch::hit
         pgpu_counters counters {};
         std::unique_ptr<detail::WorkerPool> pool;
         std::unique_ptr<detail::ThreadExchange> exchange;
@@ -532,6 +653,8 @@ private:
     GpuAccelerationStructure()
         : m(new Impl())
     {
+        Impl* const impl = m.get(); // (stays valid when the adapter object is moved)
+        m->surfaceFn = [impl](const Ray& r, uint32_t leaf, uint32_t obj, float u, float v) { return surfaceOf(*impl, r, leaf, obj, u, v); };
     }
 
     // The calling thread's buffer. The last adapter a thread used is remembered per thread, so the common case is one
@@ -590,17 +713,25 @@ private:
             float* const soa = st.hostRays;
             detail::WorkerPool::wait(m->pool->submit((n + kPiece - 1) / kPiece, [&, n, soa](size_t piece) {
                 const size_t lo = bt.lo + piece * kPiece, hi = std::min(bt.hi, lo + kPiece);
-                src.each(lo, hi, [&](const typename Gathered::Seg& g, size_t k, size_t i) {
-                    const Ray& r = g.rays[k];
-                    const size_t j = i - bt.lo;
-                    soa[j] = r.origin[0];
-                    soa[n + j] = r.origin[1];
-                    soa[2 * n + j] = r.origin[2];
-                    soa[3 * n + j] = r.direction[0];
-                    soa[4 * n + j] = r.direction[1];
-                    soa[5 * n + j] = r.direction[2];
-                    soa[6 * n + j] = r.tnear;
-                    soa[7 * n + j] = r.tfar;
+                src.eachRun(lo, hi, [&](const typename Gathered::Seg& g, size_t k0, size_t count, size_t i0) {
+                    const size_t j0 = i0 - bt.lo;
+                    if (!g.rays) { // handed over as arrays: eight copies
+                        for (size_t a = 0; a < 8; ++a)
+                            std::memcpy(soa + a * n + j0, g.soa + a * g.n + k0, count * sizeof(float));
+                        return;
+                    }
+                    for (size_t c = 0; c < count; ++c) {
+                        const Ray& r = g.rays[k0 + c];
+                        const size_t j = j0 + c;
+                        soa[j] = r.origin[0];
+                        soa[n + j] = r.origin[1];
+                        soa[2 * n + j] = r.origin[2];
+                        soa[3 * n + j] = r.direction[0];
+                        soa[4 * n + j] = r.direction[1];
+                        soa[5 * n + j] = r.direction[2];
+                        soa[6 * n + j] = r.tnear;
+                        soa[7 * n + j] = r.tfar;
+                    }
                 });
             }));
             check(pgpu_copy(dev.ctx, st.devRays, st.hostRays, 8 * n * sizeof(float), dev.copyStream), dev.ctx, "pgpu_copy (rays)");
@@ -648,6 +779,43 @@ private:
             const size_t n = bt.hi - bt.lo;
             const uint32_t* const o = dev.stage[b & 1].hostOut;
             const bool visitsValid = m->twoLevel;
+            Impl* const impl = m.get();
+            auto fillBatch = [impl, bt, n, o, visitsValid](auto& rb, const typename Gathered::Seg& g, size_t k0, size_t count, size_t i0) {
+                const size_t j0 = i0 - bt.lo;
+                rb.n = count;
+                rb.rays = g.rays ? g.rays + k0 : nullptr;
+                for (size_t a = 0; a < 8; ++a)
+                    rb.soa[a] = g.rays ? nullptr : g.soa + a * g.n + k0;
+                rb.visits = visitsValid ? o + 5 * n + j0 : nullptr;
+                rb.surfaceFn = &impl->surfaceFn;
+            };
+            if (bt.kind == PGPU_CLOSEST && m->onClosestBatch)
+                return m->pool->submit((n + kPiece - 1) / kPiece, [this, bt, n, o, fillBatch, &closest](size_t piece) {
+                    const size_t lo = bt.lo + piece * kPiece, hi = std::min(bt.hi, lo + kPiece);
+                    closest.eachRun(lo, hi, [&](const typename Gathered::Seg& g, size_t k0, size_t count, size_t i0) {
+                        const size_t j0 = i0 - bt.lo;
+                        RayBatch<HitRayState> rb;
+                        fillBatch(rb, g, k0, count, i0);
+                        rb.states = g.states + k0;
+                        rb.t = reinterpret_cast<const float*>(o) + j0;
+                        rb.obj = o + n + j0;
+                        rb.leaf = o + 2 * n + j0;
+                        rb.u = reinterpret_cast<const float*>(o + 3 * n) + j0;
+                        rb.v = reinterpret_cast<const float*>(o + 4 * n) + j0;
+                        m->onClosestBatch(rb);
+                    });
+                });
+            if (bt.kind == PGPU_ANY && m->onAnyBatch)
+                return m->pool->submit((n + kPiece - 1) / kPiece, [this, bt, n, o, fillBatch, &any](size_t piece) {
+                    const size_t lo = bt.lo + piece * kPiece, hi = std::min(bt.hi, lo + kPiece);
+                    any.eachRun(lo, hi, [&](const typename Gathered::Seg& g, size_t k0, size_t count, size_t i0) {
+                        RayBatch<AnyHitRayState> rb;
+                        fillBatch(rb, g, k0, count, i0);
+                        rb.states = g.anyStates + k0;
+                        rb.occluded = o + 6 * n + (i0 - bt.lo);
+                        m->onAnyBatch(rb);
+                    });
+                });
             if (bt.kind == PGPU_CLOSEST)
                 return m->pool->submit((n + kPiece - 1) / kPiece, [this, bt, n, o, visitsValid, &closest](size_t piece) {
                     const size_t lo = bt.lo + piece * kPiece, hi = std::min(bt.hi, lo + kPiece);
@@ -656,7 +824,7 @@ private:
                     const float* const v = reinterpret_cast<const float*>(o + 4 * n);
                     closest.each(lo, hi, [&](const typename Gathered::Seg& g, size_t k, size_t i) {
                         const size_t j = i - bt.lo;
-                        Ray r = g.rays[k];
+                        Ray r = g.ray(k);
                         if (visitsValid)
                             r.numTopLevelIntersections += o[5 * n + j];
                         if (o[n + j] == PGPU_MISS) {
@@ -671,7 +839,7 @@ private:
                 const size_t lo = bt.lo + piece * kPiece, hi = std::min(bt.hi, lo + kPiece);
                 any.each(lo, hi, [&](const typename Gathered::Seg& g, size_t k, size_t i) {
                     const size_t j = i - bt.lo;
-                    Ray r = g.rays[k];
+                    Ray r = g.ray(k);
                     if (visitsValid)
                         r.numTopLevelIntersections += o[5 * n + j];
                     if (o[6 * n + j]) {
@@ -726,10 +894,11 @@ private:
     }
 
     // what the reference's leaf does on every tentative hit (offline_bvh_cache.cpp:48-49), done once here
-    RayHit surface(const Ray& r, uint32_t leaf, uint32_t obj, float u, float v) const
+    RayHit surface(const Ray& r, uint32_t leaf, uint32_t obj, float u, float v) const { return surfaceOf(*m, r, leaf, obj, u, v); }
+    static RayHit surfaceOf(const Impl& im, const Ray& r, uint32_t leaf, uint32_t obj, float u, float v)
     {
-        const pgpu_leafobj lo = m->objsOfLeaf[leaf][obj];
-        const TriangleShape& s = (*m->shapes)[lo.mesh];
+        const pgpu_leafobj lo = im.objsOfLeaf[leaf][obj];
+        const TriangleShape& s = (*im.shapes)[lo.mesh];
         const float* p0 = &s.positions[3 * size_t(s.indices[3 * size_t(lo.prim)])];
         const float* p1 = &s.positions[3 * size_t(s.indices[3 * size_t(lo.prim) + 1])];
         const float* p2 = &s.positions[3 * size_t(s.indices[3 * size_t(lo.prim) + 2])];

@@ -129,6 +129,71 @@ static int basic()
     const int primaryHits = n - n / 10;
     if (hits != 2 * primaryHits || misses != n / 10 || anyMisses != primaryHits || anyHits != 0 || bad != 0 || traced != size_t(n + 2 * primaryHits))
         return 1;
+    // The same rays again, as arrays in (intersectBatch / intersectAnyBatch) and as runs out (setBatchHandlers): per ray the batch
+    // view must say what the per-ray handlers said -- hit or miss, shape 0 at t = 2 with the normal facing the ray, states intact.
+    std::atomic<int> bHits { 0 }, bMisses { 0 }, bBad { 0 }, bAnyHits { 0 }, bAnyMisses { 0 }, runs { 0 };
+    accel.setBatchHandlers(
+        [&](const RayBatch<BounceState>& b) {
+            ++runs;
+            for (size_t i = 0; i < b.n; ++i) {
+                const Ray r = b.ray(i);
+                const bool expectMiss = b.states[i].pixel % 10 == 9;
+                if (b.isHit(i) == expectMiss || b.rays != nullptr) {
+                    ++bBad;
+                    continue;
+                }
+                if (!b.isHit(i)) {
+                    ++bMisses;
+                    continue;
+                }
+                ++bHits;
+                const RayHit h = b.hit(i);
+                if (h.shapeID != 0 || std::fabs(r.tfar - 2.0f) > 1e-6f || std::fabs(b.t[i] - 2.0f) > 1e-6f || h.geometricNormal[2] <= 0 || r.numTopLevelIntersections == 0)
+                    ++bBad;
+            }
+        },
+        [&](const RayBatch<ShadowState>& b) {
+            for (size_t i = 0; i < b.n; ++i) {
+                const Ray r = b.ray(i);
+                if (b.isHit(i)) {
+                    ++bAnyHits;
+                    if (!(r.tfar < 0))
+                        ++bBad;
+                } else {
+                    ++bAnyMisses;
+                }
+            }
+        });
+    {
+        std::vector<float> a(8 * size_t(n));
+        std::vector<BounceState> st;
+        std::vector<ShadowState> sst;
+        for (int i = 0; i < n; ++i) {
+            a[size_t(i)] = -0.9f + 1.8f * float(i % 32) / 31.0f;
+            a[size_t(n + i)] = -0.9f + 1.8f * float(i / 32) / 31.0f;
+            a[size_t(2 * n + i)] = 1.0f;
+            a[size_t(3 * n + i)] = 0.0f;
+            a[size_t(4 * n + i)] = 0.0f;
+            a[size_t(5 * n + i)] = (i % 10 == 9) ? 1.0f : -1.0f;
+            a[size_t(6 * n + i)] = 0.0f;
+            a[size_t(7 * n + i)] = std::numeric_limits<float>::max();
+            st.push_back(BounceState { i, 0 });
+            sst.push_back(ShadowState { i });
+        }
+        const pgpu_rays soa { a.data(), a.data() + n, a.data() + 2 * n, a.data() + 3 * n, a.data() + 4 * n, a.data() + 5 * n, a.data() + 6 * n, a.data() + 7 * n };
+        // in two pieces from two threads, plus the same rays as shadow rays (every ray that looks down is occluded by quad 0)
+        std::thread t1([&] { accel.intersectBatch(soa, 600, st.data()); });
+        t1.join();
+        const pgpu_rays rest { soa.ox + 600, soa.oy + 600, soa.oz + 600, soa.dx + 600, soa.dy + 600, soa.dz + 600, soa.tnear + 600, soa.tfar + 600 };
+        accel.intersectBatch(rest, size_t(n) - 600, st.data() + 600);
+        accel.intersectAnyBatch(soa, size_t(n), sst.data());
+        if (accel.pending() != size_t(2 * n) || accel.flush() != size_t(2 * n))
+            return 1;
+    }
+    std::printf("batch interface: hits %d misses %d anyHits %d anyMisses %d bad %d in %d runs\n", bHits.load(), bMisses.load(), bAnyHits.load(), bAnyMisses.load(),
+        bBad.load(), runs.load());
+    if (bHits != primaryHits || bMisses != n / 10 || bAnyHits != primaryHits || bAnyMisses != n / 10 || bBad != 0 || runs < 2)
+        return 1;
     std::printf("adapter ok\n");
     return 0;
 }
@@ -299,14 +364,82 @@ static int throughput(size_t n, unsigned threads)
         hits += hitCells[i].v.load();
         misses += missCells[i].v.load();
     }
+    // the same rays with results delivered in runs (one handler call per <= 8192 rays; nothing computed per ray unless asked for) ...
+    std::atomic<uint64_t> bHits { 0 }, bMisses { 0 };
+    accel.setBatchHandlers(
+        [&](const RayBatch<BounceState>& b) {
+            uint64_t h = 0;
+            for (size_t i = 0; i < b.n; ++i)
+                h += b.isHit(i) ? 1u : 0u;
+            bHits.fetch_add(h, std::memory_order_relaxed);
+            bMisses.fetch_add(b.n - h, std::memory_order_relaxed);
+        },
+        [&](const RayBatch<ShadowState>&) {});
+    auto pushAll = [&] {
+        std::vector<std::thread> ps;
+        for (unsigned t = 0; t < threads; ++t)
+            ps.emplace_back([&, t] {
+                const size_t lo = n * t / threads, hi = n * (t + 1) / threads;
+                for (size_t i = lo; i < hi; ++i)
+                    accel.intersect(cameraRay(int(i)), BounceState { int(i), 0 });
+            });
+        for (auto& th : ps)
+            th.join();
+    };
+    pushAll();
+    const auto t4 = std::chrono::steady_clock::now();
+    const size_t tracedBatch = accel.flush();
+    const auto t5 = std::chrono::steady_clock::now();
+    // ... and handed over as arrays too (intersectBatch: what a wavefront integrator holds anyway)
+    std::vector<std::vector<float>> soaOf(threads);
+    std::vector<std::vector<BounceState>> statesOf(threads);
+    {
+        std::vector<std::thread> ps;
+        for (unsigned t = 0; t < threads; ++t)
+            ps.emplace_back([&, t] {
+                const size_t lo = n * t / threads, hi = n * (t + 1) / threads, m = hi - lo;
+                soaOf[t].resize(8 * m);
+                for (size_t i = lo; i < hi; ++i) {
+                    const Ray r = cameraRay(int(i));
+                    float* a = soaOf[t].data() + (i - lo);
+                    a[0] = r.origin[0], a[m] = r.origin[1], a[2 * m] = r.origin[2], a[3 * m] = r.direction[0], a[4 * m] = r.direction[1], a[5 * m] = r.direction[2];
+                    a[6 * m] = r.tnear, a[7 * m] = r.tfar;
+                    statesOf[t].push_back(BounceState { int(i), 0 });
+                }
+            });
+        for (auto& th : ps)
+            th.join();
+    }
+    const auto t6 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> ps;
+        for (unsigned t = 0; t < threads; ++t)
+            ps.emplace_back([&, t] {
+                const size_t m = statesOf[t].size();
+                const float* a = soaOf[t].data();
+                accel.intersectBatch(pgpu_rays { a, a + m, a + 2 * m, a + 3 * m, a + 4 * m, a + 5 * m, a + 6 * m, a + 7 * m }, m, statesOf[t].data());
+            });
+        for (auto& th : ps)
+            th.join();
+    }
+    const auto t7 = std::chrono::steady_clock::now();
+    const size_t tracedSoa = accel.flush();
+    const auto t8 = std::chrono::steady_clock::now();
     const double build = std::chrono::duration<double>(t1 - t0).count(), push = std::chrono::duration<double>(t2 - t1).count(),
-                 flush = std::chrono::duration<double>(t3 - t2).count();
+                 flush = std::chrono::duration<double>(t3 - t2).count(), flushBatch = std::chrono::duration<double>(t5 - t4).count(),
+                 pushSoa = std::chrono::duration<double>(t7 - t6).count(), flushSoa = std::chrono::duration<double>(t8 - t7).count();
     std::printf("{\"adapter_throughput\": {\"rays\": %zu, \"push_threads\": %u, \"host_threads\": %u, \"batching_points\": %zu, \"build_s\": %.3f, "
-                "\"push_Mrays_s\": %.1f, \"flush_Mrays_s\": %.1f, \"end_to_end_Mrays_s\": %.1f, \"hits\": %llu, \"misses\": %llu}}\n",
+                "\"push_Mrays_s\": %.1f, \"flush_Mrays_s\": %.1f, \"end_to_end_Mrays_s\": %.1f, \"flush_batch_handlers_Mrays_s\": %.1f, "
+                "\"push_arrays_Mrays_s\": %.1f, \"flush_arrays_batch_handlers_Mrays_s\": %.1f, \"end_to_end_arrays_Mrays_s\": %.1f, \"hits\": %llu, \"misses\": %llu}}\n",
         traced, threads, accel.hostThreads(), accel.numBatchingPoints(), build, double(n) / push * 1e-6, double(n) / flush * 1e-6,
-        double(n) / (push + flush) * 1e-6, (unsigned long long)hits, (unsigned long long)misses);
+        double(n) / (push + flush) * 1e-6, double(n) / flushBatch * 1e-6, double(n) / pushSoa * 1e-6, double(n) / flushSoa * 1e-6,
+        double(n) / (pushSoa + flushSoa) * 1e-6, (unsigned long long)hits, (unsigned long long)misses);
     if (traced != n || hits + misses != n || hits == 0 || misses < n / 10)
         return 1;
+    if (tracedBatch != n || tracedSoa != n || bHits.load() != 2 * hits || bMisses.load() != 2 * misses) {
+        std::printf("batch handlers disagree with the per-ray ones: %llu / %llu hits\n", (unsigned long long)bHits.load(), (unsigned long long)(2 * hits));
+        return 1;
+    }
     std::printf("adapter throughput ok\n");
     return 0;
 }
