@@ -287,6 +287,8 @@ int pgpu_init(int device_id, pgpu_ctx** out)
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("PANDORA_LEAF_DRAIN")) // (tuning knob of the streamed loop's queue policy, top_abi.hip; results do not depend on it)
         c->leafDrainRatio = float(std::atof(e));
+    if (const char* e = std::getenv("PANDORA_LEAF_PREFETCH"))
+        c->leafPrefetchBytesPerRay = float(std::atof(e));
     if (initStaticScratch(c) != PGPU_OK) {
         pgpu_shutdown(c);
         return PGPU_ERR_HIP;

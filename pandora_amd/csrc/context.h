@@ -102,6 +102,7 @@ struct pgpu_ctx {
     std::deque<uint32_t> ring;
     uint64_t groupClock = 0;
     uint32_t leafHoldBytesPerRay = 256; // pgpu_set_leaf_hold: an image that is not in the cache is loaded once its point holds a ray per this many bytes (0: always)
+    float leafPrefetchBytesPerRay = 0.0f; // waiting points are loaded early up to this many bytes of image per moving ray and round (PANDORA_LEAF_PREFETCH)
     float leafDrainRatio = 4.0f; // waiting queues are flushed as well once they hold more than this many times the rays that still move (PANDORA_LEAF_DRAIN)
     int leafCopyMode = 0;   // pgpu_set_leaf_copy: 0 = one gather kernel per launch group reads the pinned images, 1 = one hipMemcpyAsync per image
     void* copyTableHost = nullptr; // pinned: the gather kernel's segments and the BVH-table entries that changed, one run per launch group

@@ -1076,7 +1076,12 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                     raysWaiting += hLeafCount[l];
                 }
             }
-            if (nWaiting && (nTraced == 0 || double(raysWaiting) > c->leafDrainRatio * double(raysOn))) {
+            // (prefetch: while many rays move, a round's launches are long and the copy engine idles -- room to bring in waiting
+            // points early, leafPrefetchBytesPerRay bytes of image per moving ray, fullest queues first)
+            const size_t prefetchBudget = size_t(double(c->leafPrefetchBytesPerRay) * double(raysOn));
+            const bool drain = nTraced == 0 || double(raysWaiting) > c->leafDrainRatio * double(raysOn);
+            if (nWaiting && (drain || loadBytes < prefetchBudget)) {
+                const size_t limit = drain ? c->cacheBytes : std::min(c->cacheBytes, prefetchBudget);
                 visitOrder.clear();
                 for (size_t l = 0; l < nl; ++l)
                     if (hLeafCount[l] != 0 && !traced[l])
@@ -1087,7 +1092,7 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
                 });
                 for (uint32_t l : visitOrder) {
                     const size_t b = alignUp(stagedImage(l)->imageBytes());
-                    if (nTraced && loadBytes + b > c->cacheBytes)
+                    if (nTraced && loadBytes + b > limit)
                         break;
                     loadBytes += b;
                     traced[l] = 1;
