@@ -475,6 +475,14 @@ int pgpu_set_ray_layout(pgpu_ctx*, int lanes_per_ray);
  * kernels take their list lengths from device memory), so the GPU never waits for that read; 0 restores the round-by-round
  * loop, which streamed scenes and pgpu_set_svdag_defer always use. On by default. Results do not depend on it. */
 int pgpu_set_round_lookahead(pgpu_ctx*, int on);
+/* pgpu_trace on resident scenes runs a large batch as `parts` batches side by side, each on a stream of its own (2..4; 1 = never;
+ * 0 = the default: two parts from 2^21 rays on). A round is a chain of kernels of opposite character -- the top-level episode waits
+ * on memory, the bottom level on instruction issue -- and every one of them ends in a tail that leaves CUs idle: two chains fill each
+ * other's gaps. The parts have work buffers of their own and share the scene; pgpu_counters adds up
+ * (rounds: the largest), pgpu_last_kernel_ms is the longest part. Applies when the look-ahead loop does (pgpu_set_round_lookahead),
+ * to host and device batches alike. Results do not depend on it: rays do not interact.
+ * (No counterpart in the reference, whose CPU tasks already run side by side, task_graph.h:259-292.) */
+int pgpu_set_batch_parts(pgpu_ctx*, int parts);
 /* The top-level kernel of pgpu_trace: 1 = waves in lockstep (64 rays start an episode together and the wave waits for the
  * slowest), 2 = lanes take the next ray as soon as theirs has parked or left, and a wave runs BVH4 steps and SVDAG cast trips
  * as separate phases, 3 = lockstep waves for a trace's first episode (every ray from the root) and variant 2 for the resumed rays

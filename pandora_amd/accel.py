@@ -620,6 +620,11 @@ class Context:
         one host read per round before the next is queued. Same results."""
         _check(self._L.pgpu_set_round_lookahead(self._h, int(on)), self._h)
 
+    def set_batch_parts(self, parts: int = 0):
+        """trace() on resident scenes runs a large batch as `parts` batches side by side on streams of their own (2..4; 1 = never;
+        0 = default: two parts from 2^21 rays on). Same results."""
+        _check(self._L.pgpu_set_batch_parts(self._h, int(parts)), self._h)
+
     def set_svdag_defer(self, min_rays: int = 0, passes: int = 2):
         """Where trace() runs the SVDAG casts: 0 = inside the top-level episode (default); > 0 = passes of at least that many
         rays cast in a kernel of their own, `passes` times per round (pgpu_set_svdag_defer). Same results bit for bit."""

@@ -305,6 +305,9 @@ void pgpu_shutdown(pgpu_ctx* c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     destroyComm(c);
+    destroyLanes(c);
+    if (c->lanesFork)
+        (void)hipEventDestroy(c->lanesFork);
     for (void* p : c->owned)
         (void)hipFree(p);
     if (c->bvhTable)

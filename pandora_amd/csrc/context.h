@@ -124,6 +124,11 @@ struct pgpu_ctx {
     uint32_t* roundCounts = nullptr;
     size_t roundCountsCap = 0;
     hipEvent_t roundEv[2] = { nullptr, nullptr };
+    // pgpu_trace runs a large batch as parts side by side (pgpu_set_batch_parts): the contexts of the parts beyond the first.
+    // They share this context's scene and own only their streams and work buffers (top_abi.hip)
+    int batchParts = 0; // 0 = automatic
+    std::vector<pgpu_ctx*> lanes;
+    hipEvent_t lanesFork = nullptr;
     std::vector<hipEvent_t> launchEvents; // ring: one event per bottom-level launch of the streaming path (a later record of the
     size_t launchEventNext = 0;           // same ring entry is a later point of the compute stream, so waiting on it stays safe)
 };
@@ -171,6 +176,8 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
 // grows the scratch of traceLeafRecords (and the given overflow buffer) for up to k records, so that the call itself cannot fail on memory
 int reserveLeafRecords(pgpu_ctx* c, size_t k, DeviceBuffer* spill);
 void destroyComm(pgpu_ctx* c); // sharded_abi.hip
+void destroyLanes(pgpu_ctx* c); // top_abi.hip
+constexpr size_t kBatchPartsAutoMin = size_t(1) << 21; // batches of at least this many rays are cut in two unless told otherwise
 }
 
 #define HIP_TRY(ctx, call)                                            \

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 using namespace pandora_hip;
 
@@ -562,7 +563,8 @@ int pgpu_upload_top_bvh4(pgpu_ctx* c, const void* nodes112, size_t n_nodes, uint
     return rebuildLeafDags(c);
 }
 
-int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
+// One batch through the round loop on one context (pgpu_trace below runs a large batch as several of these side by side).
+static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
     const pgpu_hits* hits, uint32_t* any_hit, pgpu_counters* counters, void* stream_)
 {
     const TraceRange range_("pgpu_trace");
@@ -1192,6 +1194,179 @@ int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_
     }
     if (counters)
         *counters = c->counters;
+    return PGPU_OK;
+}
+
+// ---- a large batch as parts side by side ---------------------------------------------------------------------------------
+// A round of the loop above is a chain of kernels of opposite character -- the top-level episode is bound by memory latency
+// (few waves per CU, every lane chasing its own nodes), the bottom level by instruction issue -- and each of them ends in a
+// tail in which most CUs idle. Two chains over half the rays each, on two streams, fill each other's gaps: the GPU runs the
+// one's episode next to the other's bottom level (profiles/r3_overlap_halves.txt). Rays do not interact, so the results are the
+// same whichever way a batch is cut. A part runs on a "lane": a context of its own (stream, work buffers, cursors, pinned
+// counts) that shares the scene -- the device pointers -- with the context it belongs to and owns none of it.
+namespace {
+pgpu_ctx* newLane(pgpu_ctx* c)
+{
+    pgpu_ctx* l = new (std::nothrow) pgpu_ctx();
+    if (!l)
+        return nullptr;
+    l->device = c->device;
+    l->numCUs = c->numCUs;
+    hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreate(&l->ev0);
+    if (e == hipSuccess)
+        e = hipEventCreate(&l->ev1);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&l->cursor), 512);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&l->statsDev), 64);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&l->topCounters), 64);
+    if (e != hipSuccess) {
+        pgpu_shutdown(l); // (owns nothing of the scene yet)
+        return nullptr;
+    }
+    return l;
+}
+
+// the scene and the settings as the owning context has them now (pointers and small host tables: no device work)
+void refreshLane(pgpu_ctx* l, const pgpu_ctx* c)
+{
+    l->blocksPerCU = c->blocksPerCU;
+    l->chunk = c->chunk;
+    l->refillMin = c->refillMin;
+    l->lanesPerRay = c->lanesPerRay;
+    l->leafMin = c->leafMin;
+    l->stackWindow = c->stackWindow;
+    l->svdagPolicy = c->svdagPolicy;
+    l->hasInstances = c->hasInstances;
+    l->bvhs = c->bvhs;
+    l->bvhTable = c->bvhTable;
+    l->bvhTableCap = c->bvhTableCap;
+    l->bvhTableDirty = false;
+    l->top = c->top;
+    l->haveTop = c->haveTop;
+    l->topVariant = c->topVariant;
+    l->topRefillMin = c->topRefillMin;
+    l->topCastTrips = c->topCastTrips;
+    l->roundLookahead = true;
+}
+}
+
+} // extern "C"
+void pandora_hip::destroyLanes(pgpu_ctx* c)
+{
+    for (pgpu_ctx* l : c->lanes) {
+        l->bvhTable = nullptr; // the scene belongs to c
+        l->bvhs.clear();
+        pgpu_shutdown(l);
+    }
+    c->lanes.clear();
+}
+extern "C" {
+
+int pgpu_set_batch_parts(pgpu_ctx* c, int parts)
+{
+    if (!c || parts < 0 || parts > 4)
+        return PGPU_ERR_INVALID;
+    c->batchParts = parts;
+    return PGPU_OK;
+}
+
+int pgpu_trace(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays, size_t n, int mem,
+    const pgpu_hits* hits, uint32_t* any_hit, pgpu_counters* counters, void* stream_)
+{
+    // Which batches are cut: resident scenes on the look-ahead loop (the parts then never wait for the host inside a round), no
+    // per-kernel statistics (one set of counters), and enough rays that each part still fills the GPU. Everything else -- and
+    // every argument error -- goes through traceBatch as it is.
+    size_t parts = c ? (c->batchParts ? size_t(c->batchParts) : (n >= kBatchPartsAutoMin ? 2u : 1u)) : 1u;
+    const bool pairLists = c && (c->hasInstances || c->lanesPerRay == 0u || c->lanesPerRay == 2u);
+    const bool argsOk = c && rays && (kind == PGPU_CLOSEST || kind == PGPU_ANY) && (mem == PGPU_MEM_HOST || mem == PGPU_MEM_DEVICE)
+        && (kind == PGPU_ANY ? any_hit != nullptr : (hits && hits->t && hits->obj && hits->leaf && hits->u && hits->v))
+        && rays->ox && rays->oy && rays->oz && rays->dx && rays->dy && rays->dz && rays->tnear && rays->tfar && n <= 0x3FFFFFFFull;
+    if (!argsOk || parts < 2 || n < parts * 65536 || !c->haveTop || c->topHasRemoteLeaves || c->nStaged > 0 || c->deferMin != 0u || !c->roundLookahead
+        || !pairLists || c->stats)
+        return traceBatch(c, kind, tri_mode, rays, n, mem, hits, any_hit, counters, stream_);
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        const int rt = syncBvhTable(c);
+        if (rt != PGPU_OK)
+            return rt;
+    }
+    while (c->lanes.size() + 1 < parts) {
+        pgpu_ctx* l = newLane(c);
+        if (!l)
+            return fail(c, PGPU_ERR_HIP, "pgpu_trace: could not set up a lane for a part of the batch");
+        c->lanes.push_back(l);
+    }
+    hipStream_t stream = (mem == PGPU_MEM_DEVICE && stream_) ? static_cast<hipStream_t>(stream_) : c->stream;
+    if (!c->lanesFork)
+        HIP_TRY(c, hipEventCreateWithFlags(&c->lanesFork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->lanesFork, stream)); // whatever produced the rays on the caller's stream comes first
+    const size_t per = ((n + parts - 1) / parts + 255) & ~size_t(255);
+    struct Part {
+        pgpu_rays rays;
+        pgpu_hits hits;
+        uint32_t* any = nullptr;
+        size_t n = 0;
+        pgpu_counters counters {};
+        int rc = PGPU_OK;
+    };
+    std::vector<Part> part(parts);
+    for (size_t p = 0; p < parts; ++p) {
+        const size_t at = std::min(n, p * per);
+        Part& q = part[p];
+        q.n = std::min(n - at, per);
+        q.rays = pgpu_rays { rays->ox + at, rays->oy + at, rays->oz + at, rays->dx + at, rays->dy + at, rays->dz + at, rays->tnear + at, rays->tfar + at };
+        q.hits = pgpu_hits {};
+        if (hits) {
+            q.hits.t = hits->t ? hits->t + at : nullptr;
+            q.hits.obj = hits->obj ? hits->obj + at : nullptr;
+            q.hits.leaf = hits->leaf ? hits->leaf + at : nullptr;
+            q.hits.u = hits->u ? hits->u + at : nullptr;
+            q.hits.v = hits->v ? hits->v + at : nullptr;
+            q.hits.visits = hits->visits ? hits->visits + at : nullptr;
+            q.hits.inst = hits->inst ? hits->inst + at : nullptr;
+        }
+        q.any = any_hit ? any_hit + at : nullptr;
+    }
+    std::vector<std::thread> threads;
+    for (size_t p = 1; p < parts; ++p) {
+        pgpu_ctx* l = c->lanes[p - 1];
+        refreshLane(l, c);
+        HIP_TRY(c, hipStreamWaitEvent(l->stream, c->lanesFork, 0));
+    }
+    for (size_t p = 1; p < parts; ++p)
+        threads.emplace_back([&, p] {
+            Part& q = part[p];
+            pgpu_ctx* l = c->lanes[p - 1];
+            q.rc = traceBatch(l, kind, tri_mode, &q.rays, q.n, mem, hits ? &q.hits : nullptr, q.any, &q.counters, l->stream);
+        });
+    part[0].rc = traceBatch(c, kind, tri_mode, &part[0].rays, part[0].n, mem, hits ? &part[0].hits : nullptr, part[0].any, &part[0].counters, stream_);
+    for (std::thread& t : threads)
+        t.join(); // (traceBatch returns with its stream drained: every part's results are in place)
+    pgpu_counters sum {};
+    float ms = c->lastKernelMs;
+    for (size_t p = 0; p < parts; ++p) {
+        const Part& q = part[p];
+        if (q.rc != PGPU_OK) {
+            if (p > 0)
+                c->err = c->lanes[p - 1]->err;
+            return q.rc;
+        }
+        sum.svdag_tests += q.counters.svdag_tests;
+        sum.svdag_culled += q.counters.svdag_culled;
+        sum.leaf_visits += q.counters.leaf_visits;
+        sum.rounds = std::max(sum.rounds, q.counters.rounds);
+        if (p > 0)
+            ms = std::max(ms, c->lanes[p - 1]->lastKernelMs);
+    }
+    c->lastKernelMs = ms; // (the parts start together: the longest one is the trace)
+    c->counters = sum;
+    if (counters)
+        *counters = sum;
     return PGPU_OK;
 }
 

@@ -116,6 +116,43 @@ def test_top_level_lanes_kernel_matches_oracle(two_level, refill_min, cast_trips
         ctx.set_round_lookahead(True)
 
 
+@pytest.mark.parametrize("parts", [2, 3, 4])
+def test_a_batch_cut_into_parts_matches_oracle(two_level, parts):
+    """pgpu_set_batch_parts: a batch as several batches side by side on their own streams and work buffers -- same hits, visit
+    counts and summed counters as the oracle on the whole batch, from host arrays and from device arrays, closest and any hit;
+    a length that is no multiple of anything."""
+    import torch
+    ctx, mesh, tl, orc = two_level
+    ctx.set_ray_layout(0)
+    ctx.set_kernel_variant(0, 0, 0)
+    n = 4 * 65536 + 4097
+    rays = np.ascontiguousarray(np.concatenate([
+        pa.scenes.random_rays((-3, -1, -3), (3, 3, 3), n - 50000, seed=11),
+        pa.scenes.random_rays((-300, -300, -300), (300, 300, 300), 50000, seed=12, toward=((-1, 0, -1), (1, 2, 1)))], axis=1))
+    want = orc.trace(rays, lanes=3)
+    want_any = orc.trace(rays, any_hit=True, lanes=3)
+    ctx.set_batch_parts(parts)
+    try:
+        for src in (rays, torch.from_numpy(rays).cuda()):
+            got, cnt = ctx.trace(src)
+            for k in ("t", "obj", "leaf", "u", "v", "visits"):
+                g = got[k].cpu().numpy() if torch.is_tensor(got[k]) else got[k]
+                bad = np.nonzero(_bits(g) != _bits(want[k]))[0]
+                assert bad.size == 0, f"{k} differs on {bad.size} rays, first {bad[:5]}"
+            for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                assert cnt[k] == want["counters"][k], f"counter {k}: {cnt[k]} != {want['counters'][k]}"
+            assert cnt["rounds"] >= 1
+            got_any, cnt_any = ctx.trace(src, kind=pa.capi.ANY)
+            for k in ("hit", "visits"):
+                g = got_any[k].cpu().numpy() if torch.is_tensor(got_any[k]) else got_any[k]
+                assert np.array_equal(_bits(g), _bits(want_any[k])), f"any-hit {k} differs"
+            for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+                assert cnt_any[k] == want_any["counters"][k], f"any counter {k}"
+        assert ctx.last_kernel_ms() > 0
+    finally:
+        ctx.set_batch_parts(0)
+
+
 @pytest.mark.parametrize("n", [1, 63, 256, 257, 1025])
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_tiny_batches_through_the_round_loop(two_level, n, variant):
