@@ -286,6 +286,217 @@ struct Bvh8Builder {
         return handleLeaf(at, uint32_t(p.count()));
     }
 
+    // ---- second construction: a binary SAH tree down to single objects, collapsed into 8-wide nodes by dynamic programming
+    // (Ylitie, Karras, Laine 2017, section 3: the cheapest wide tree that a given binary tree contains). The greedy
+    // construction below splits whichever part is largest until a node has 8 children and turns every part of at most maxLeaf
+    // objects into a leaf on sight: near the bottom that leaves nodes with two or three leaves under parents whose slots are
+    // taken (3.96 children per node on the benchmark atrium). The collapse decides per binary subtree whether it becomes a
+    // leaf, one wide node, or several children of its ancestor's wide node, by what the traversal pays: a node visit per unit of
+    // surface area, a leaf visit likewise (a leaf of up to four triangles is one step of the traversal kernels).
+    struct Bin {
+        size_t begin, end;
+        Box box;
+        int left = -1, right = -1;
+        float cost[9];   // cost[j]: cheapest forest of at most j wide-tree roots (leaves or nodes) that covers this subtree; [1] = one root
+        uint8_t cut[9];  // cut[j] (j >= 2): roots given to the left subtree; 0 = the subtree stays one root
+        uint8_t inner1;  // the one-root form is a wide node (1) or a leaf (0)
+        uint8_t kLeft;   // one-root wide node: roots taken from the left subtree (the rest of the 8 from the right)
+        uint8_t height;  // inner nodes on the longest path of the one-root form
+    };
+    std::vector<Bin> bins;
+    float costInner = 1.0f, costLeaf = 1.0f, costObject = 0.0f;
+
+    // exact SAH over the three axes for small ranges (sorted sweep), binned above that
+    size_t splitBinary(size_t begin, size_t end, bool forceMedian)
+    {
+        const size_t n = end - begin;
+        if (n > 64 || forceMedian)
+            return splitPart(items, begin, end, forceMedian);
+        int bestAxis = -1;
+        size_t bestAt = 0;
+        float bestCost = FLT_MAX;
+        std::vector<float> rightArea(n);
+        for (int a = 0; a < 3; ++a) {
+            std::sort(items.begin() + begin, items.begin() + end,
+                [a](const Item& x, const Item& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.id < y.id); });
+            Box acc;
+            for (size_t i = n - 1; i > 0; --i) {
+                acc.grow(items[begin + i].box);
+                rightArea[i] = acc.halfArea();
+            }
+            acc = Box();
+            for (size_t i = 0; i + 1 < n; ++i) {
+                acc.grow(items[begin + i].box);
+                const float cost = acc.halfArea() * float(i + 1) + rightArea[i + 1] * float(n - i - 1);
+                if (cost < bestCost) {
+                    bestCost = cost;
+                    bestAxis = a;
+                    bestAt = i + 1;
+                }
+            }
+        }
+        if (bestAxis != 2)
+            std::sort(items.begin() + begin, items.begin() + end,
+                [bestAxis](const Item& x, const Item& y) { return x.c[bestAxis] < y.c[bestAxis] || (x.c[bestAxis] == y.c[bestAxis] && x.id < y.id); });
+        return begin + bestAt;
+    }
+
+    int buildBinary(size_t begin, size_t end, int depth = 0)
+    {
+        const int self = int(bins.size());
+        bins.emplace_back();
+        bins[size_t(self)].begin = begin;
+        bins[size_t(self)].end = end;
+        bins[size_t(self)].box = boundsOf(items, begin, end);
+        if (end - begin > 1) {
+            const size_t m = splitBinary(begin, end, depth > 48); // (a chain of lopsided splits ends in balanced ones)
+            const int l = buildBinary(begin, m, depth + 1);
+            const int r = buildBinary(m, end, depth + 1);
+            bins[size_t(self)].left = l;
+            bins[size_t(self)].right = r;
+        }
+        return self;
+    }
+
+    void solve(int at)
+    {
+        // (children first; the binary tree is as deep as the splits make it, so no recursion here: nodes were created parent first)
+        for (int i = int(bins.size()) - 1; i >= at; --i) {
+            Bin& b = bins[size_t(i)];
+            const size_t n = b.end - b.begin;
+            const float area = b.box.halfArea();
+            const float asLeaf = leafable(items, b.begin, b.end, maxLeaf) ? area * (costLeaf + costObject * float(n)) : FLT_MAX;
+            if (b.left < 0) {
+                for (int j = 1; j <= 8; ++j) {
+                    b.cost[j] = asLeaf;
+                    b.cut[j] = 0;
+                }
+                b.inner1 = 0;
+                b.kLeft = 0;
+                b.height = 0;
+                continue;
+            }
+            const Bin &l = bins[size_t(b.left)], &r = bins[size_t(b.right)];
+            float bestKids = FLT_MAX;
+            uint8_t bestK = 1;
+            for (int k = 1; k <= 7; ++k) {
+                const float c = l.cost[k] + r.cost[8 - k];
+                if (c < bestKids) {
+                    bestKids = c;
+                    bestK = uint8_t(k);
+                }
+            }
+            const float asInner = area * costInner + bestKids;
+            b.inner1 = asInner < asLeaf ? 1 : 0;
+            b.kLeft = bestK;
+            b.cost[1] = std::min(asInner, asLeaf);
+            b.cut[1] = 0;
+            for (int j = 2; j <= 8; ++j) {
+                float best = b.cost[1];
+                uint8_t cut = 0;
+                for (int k = 1; k < j; ++k) {
+                    const float c = l.cost[k] + r.cost[j - k];
+                    if (c < best) {
+                        best = c;
+                        cut = uint8_t(k);
+                    }
+                }
+                b.cost[j] = best;
+                b.cut[j] = cut;
+            }
+            b.height = 0;
+            if (b.inner1) {
+                int roots[8];
+                const int nr = gather(b.left, b.kLeft, roots, 0);
+                const int nn = gather(b.right, 8 - b.kLeft, roots, nr);
+                uint8_t h = 0;
+                for (int q = 0; q < nn; ++q)
+                    h = std::max(h, bins[size_t(roots[q])].height);
+                b.height = uint8_t(std::min(255, int(h) + 1));
+            }
+        }
+    }
+
+    // the roots of the cheapest forest of at most j roots under binary node i
+    int gather(int i, int j, int* roots, int n) const
+    {
+        const Bin& b = bins[size_t(i)];
+        if (j <= 1 || b.cut[j] == 0) {
+            roots[n] = i;
+            return n + 1;
+        }
+        n = gather(b.left, b.cut[j], roots, n);
+        return gather(b.right, j - b.cut[j], roots, n);
+    }
+
+    uint32_t emitCollapsed(int i, int depth)
+    {
+        const Bin b = bins[size_t(i)];
+        if (!b.inner1)
+            return emitLeaf(Part { b.begin, b.end, b.box });
+        maxDepthSeen = std::max(maxDepthSeen, depth + 1);
+        int roots[8];
+        const int nl = gather(b.left, b.kLeft, roots, 0);
+        const unsigned n = unsigned(gather(b.right, 8 - b.kLeft, roots, nl));
+        const uint32_t self = uint32_t(nodes.size());
+        nodes.emplace_back();
+        Box kids[8];
+        uint32_t handles[8];
+        for (unsigned q = 0; q < n; ++q) {
+            kids[q] = bins[size_t(roots[q])].box;
+            handles[q] = emitCollapsed(roots[q], depth + 1);
+        }
+        fillNode(self, kids, handles, n);
+        return handleInner(self);
+    }
+
+    // false: the collapsed tree would nest deeper than the traversal stack allows (the caller falls back to the greedy construction,
+    // which balances its splits against that budget)
+    bool buildCollapsed(const Part& whole, uint32_t* root)
+    {
+        bins.clear();
+        bins.reserve(2 * whole.count());
+        buildBinary(whole.begin, whole.end);
+        solve(0);
+        if (int(bins[0].height) > kMaxInnerDepth8) {
+            bins.clear();
+            return false;
+        }
+        *root = emitCollapsed(0, 0);
+        bins.clear();
+        bins.shrink_to_fit();
+        return true;
+    }
+
+    void fillNode(uint32_t self, const Box* kids, const uint32_t* handles, unsigned n)
+    {
+        Node8& nd = nodes[self];
+        std::memset(&nd, 0, sizeof(nd)); // absent children: zero boxes, handle 0 (wive_bvh8_build8_impl.h:142-144,168-170)
+        for (unsigned i = 0; i < n; ++i) {
+            nd.minX[i] = kids[i].lo[0];
+            nd.maxX[i] = kids[i].hi[0];
+            nd.minY[i] = kids[i].lo[1];
+            nd.maxY[i] = kids[i].hi[1];
+            nd.minZ[i] = kids[i].lo[2];
+            nd.maxZ[i] = kids[i].hi[2];
+            nd.children[i] = handles[i];
+        }
+        octantPermutation(kids, n, nd.perm);
+    }
+
+    uint32_t buildTree(const Part& whole)
+    {
+        const char* e = std::getenv("PANDORA_BVH8_BUILDER");
+        if (const char* v = std::getenv("PANDORA_SAH_LEAF"))
+            costLeaf = float(std::atof(v));
+        if (const char* v = std::getenv("PANDORA_SAH_OBJECT"))
+            costObject = float(std::atof(v));
+        uint32_t root = 0;
+        if (!(e && std::strcmp(e, "greedy") == 0) && buildCollapsed(whole, &root))
+            return root;
+        return build(whole, 0);
+    }
+
     // depth = number of inner nodes above this one
     uint32_t build(const Part& whole, int depth)
     {
@@ -304,18 +515,7 @@ struct Bvh8Builder {
             kids[i] = parts[i].box;
             handles[i] = build(parts[i], depth + 1);
         }
-        Node8& nd = nodes[self];
-        std::memset(&nd, 0, sizeof(nd)); // absent children: zero boxes, handle 0 (wive_bvh8_build8_impl.h:142-144,168-170)
-        for (unsigned i = 0; i < n; ++i) {
-            nd.minX[i] = kids[i].lo[0];
-            nd.maxX[i] = kids[i].hi[0];
-            nd.minY[i] = kids[i].lo[1];
-            nd.maxY[i] = kids[i].hi[1];
-            nd.minZ[i] = kids[i].lo[2];
-            nd.maxZ[i] = kids[i].hi[2];
-            nd.children[i] = handles[i];
-        }
-        octantPermutation(kids, n, nd.perm);
+        fillNode(self, kids, handles, n);
         return handleInner(self);
     }
 };
@@ -434,7 +634,7 @@ int pgpu_build_bvh8(const float* positions, size_t n_vertices, const uint32_t* i
         b.items.push_back(triangleItem(positions, indices, prim_ids ? prim_ids[j] : uint32_t(j), uint32_t(j)));
     Part whole { 0, n_prims, boundsOf(b.items, 0, n_prims) };
     auto* r = new pgpu_host_bvh8();
-    r->v.root = b.build(whole, 0);
+    r->v.root = b.buildTree(whole);
     r->v.nodes = std::move(b.nodes);
     r->v.leafIdx = std::move(b.leafIdx);
     r->v.depth = b.maxDepthSeen;
@@ -463,7 +663,7 @@ int pgpu_build_bvh8_boxes(const float* bounds6, size_t n_objects, const uint8_t*
     }
     Part whole { 0, n_objects, boundsOf(b.items, 0, n_objects) };
     auto* r = new pgpu_host_bvh8();
-    r->v.root = b.build(whole, 0);
+    r->v.root = b.buildTree(whole);
     r->v.nodes = std::move(b.nodes);
     r->v.leafIdx = std::move(b.leafIdx);
     r->v.depth = b.maxDepthSeen;
