@@ -380,32 +380,54 @@ def run_landscape(args, pa, torch, ctx, dev, rank):
     return step, n, finish
 
 
+def sharded_scene(args, pa, dist, rank, world, blocks, svdag, svdag_ctx=None):
+    """The sharded record's scene, built rank-locally: the city as tiles (scenes.CityTiles: a tile = a batching point), owners
+    decided from the tiles' triangle counts -- known without making them --, every rank makes geometry, BVH8s and SVDAGs of its
+    own tiles only, the ranks exchange the tiles' bounds and DAGs and each assembles the top level (accel.tiles_assemble).
+    -> (tiles, two-level scene, owner per tile, this rank's part, seconds spent)"""
+    from pandora_amd import sharded
+    t0 = time.perf_counter()
+    tiles = pa.scenes.CityTiles(blocks, 18750)
+    w = tiles.weights()
+    if args.sharded_owners == "contiguous":  # runs of a Z-order curve over the tile grid, balanced by triangle count
+        cells = np.array([tiles.tile_cell(t) for t in range(tiles.n_tiles)], np.int64)
+        key = np.zeros(tiles.n_tiles, np.int64)
+        for b in range(16):
+            key |= ((cells[:, 0] >> b) & 1) << (2 * b + 1) | ((cells[:, 1] >> b) & 1) << (2 * b)
+        order = np.argsort(key, kind="stable")
+        owner_by_tile = np.empty(tiles.n_tiles, np.int64)
+        owner_by_tile[order] = sharded.assign_leaves_contiguous(w[order], world)
+    else:
+        owner_by_tile = np.asarray(sharded.assign_leaves(w, world), np.int64)  # balanced by triangle count
+    part = pa.accel.tiles_local_part(tiles, owner_by_tile == rank, svdag_res=svdag, svdag_device_ctx=svdag_ctx)
+    mine = {k: part[k] for k in pa.accel.TILE_SHARED_KEYS}
+    if world > 1:
+        shared = [None] * world
+        dist.all_gather_object(shared, mine)
+    else:
+        shared = [mine]
+    tl = pa.accel.tiles_assemble(tiles.n_tiles, shared, part)
+    return tiles, tl, owner_by_tile, part, time.perf_counter() - t0
+
+
 def run_sharded(args, pa, torch, dist, dev, rank, world):
     """configs[3]: batching points sharded over the ranks' HBM, records routed by RCCL (pgpu_trace_sharded). Every rank
-    builds only the BVHs of its own batching points. Returns the `sharded` record (rank 0) or None."""
+    makes only the geometry and the BVHs of its own batching points. Returns the `sharded` record (rank 0) or None."""
     from pandora_amd import sharded
-    owner_by_group = {}
-
-    def mine(sizes, top):  # deterministic on every rank
-        if args.sharded_owners == "contiguous":
-            order = np.asarray(top.leaf_order, np.int64)
-            owner_by_group["o"] = np.empty(len(sizes), np.int64)
-            owner_by_group["o"][order] = sharded.assign_leaves_contiguous(np.asarray(sizes)[order], world)
-        else:
-            owner_by_group["o"] = sharded.assign_leaves(sizes, world)  # balanced by triangle count
-        return owner_by_group["o"] == rank
-
     t0 = time.perf_counter()
     ctx = pa.accel.Context(dev.index)
-    mesh, tl = city_scene(pa, args.sharded_blocks, build_group=mine, svdag=args.svdag, ctx=ctx)
-    owner = owner_by_group["o"][np.asarray(tl.top.leaf_order, np.int64)]  # per leaf slot
-    # (only the triangles of this rank's batching points go to its HBM)
-    part_pos, part_idx, remap = tl.sub_mesh(mesh.pos, mesh.idx, owner == rank)
+    tiles, tl, owner_by_tile, part, scene_s = sharded_scene(args, pa, dist, rank, world, args.sharded_blocks, args.svdag, svdag_ctx=ctx)
+    print("rank %d: scene_build_s %.1f (%d of %d tiles, %d triangles)" % (rank, scene_s, len(part["tiles"]), tiles.n_tiles, part["idx"].shape[0]), file=sys.stderr, flush=True)
+    leaf_tile = np.asarray(tl.top.leaf_order, np.int64)  # tile (= group) per leaf slot
+    owner = owner_by_tile[leaf_tile]
+    part_pos, part_idx = part["pos"], part["idx"]
+    n_tris_total = int(tiles.weights().sum())
     if part_idx.shape[0] == 0:  # (a rank without batching points still needs a mesh to name)
         part_pos, part_idx = np.zeros((3, 3), np.float32), np.array([[0, 1, 2]], np.uint32)
-    tl.upload(ctx, ctx.upload_mesh(part_pos, part_idx), resident=(owner == rank), prim_remap=remap)
+    tl.upload(ctx, ctx.upload_mesh(part_pos, part_idx), resident=(owner == rank))
     mesh_bytes = float(part_pos.nbytes + part_idx.nbytes)
-    del part_pos, part_idx, remap
+    part["pos"] = part["idx"] = None
+    del part_pos, part_idx
     sharded.comm_init(ctx, dev)  # RCCL communicator of the library's own; the unique id travels through torch.distributed
     ctx.comm_selftest()
     ctx.set_leaf_owners(owner)
@@ -413,8 +435,13 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
     build_s = time.perf_counter() - t0
     prim = city_camera(pa, args.sharded_blocks, args.sharded_side, 891379 + 7919 * rank)
     first, _ = ctx.trace_sharded(torch.from_numpy(prim).to(dev))
-    prim_id = tl.prim_ids_of(first["leaf"].cpu().numpy(), first["obj"].cpu().numpy())
-    rays = pa.scenes.diffuse_bounce_rays(mesh, prim, first["t"].cpu().numpy(), prim_id, seed=891379 + 7919 * rank)
+    # the bounce needs the normal of whatever was hit, on any rank's tiles: the tiles this rank's camera sees are made once more here
+    f_obj, f_leaf = first["obj"].cpu().numpy().view(np.uint32), first["leaf"].cpu().numpy().view(np.uint32)
+    hit = np.nonzero(f_obj != MISS)[0]
+    normals = np.zeros((f_obj.size, 3), np.float64)
+    normals[hit] = tiles.normals_of(leaf_tile[f_leaf[hit].astype(np.int64)], f_obj[hit])
+    rays = pa.scenes.diffuse_bounce_rays(None, prim, first["t"].cpu().numpy(), f_obj, seed=891379 + 7919 * rank, normals=normals)
+    del normals, first
     d_rays = torch.from_numpy(rays).to(dev)
     n = int(rays.shape[1])
     out, cnt = ctx.trace_sharded(d_rays)  # warm-up, allocates the result arrays and the record buffers
@@ -442,13 +469,14 @@ def run_sharded(args, pa, torch, dist, dev, rank, world):
     if rank == 0:
         total_rays, visits, routed, xbytes, ranks, resident, mesh_total = (float(x) for x in sums.tolist())
         el = float(mx.item())
-        rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, %d^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (mesh.n_tris, tl.n_leaves, args.svdag, world),
+        rec = {"workload": "configs[3]-class: synthetic city (%d triangles, %d batching points, %d^3 SVDAGs), batching points sharded over %d GPUs' HBM, R-diffuse closest-hit, records routed by all-to-all" % (n_tris_total, tl.n_leaves, args.svdag, world),
                "engine": "pgpu_trace_sharded (C ABI, RCCL grouped ncclSend/ncclRecv)", "owners": args.sharded_owners, "svdag_policy": args.svdag_policy, "torch_backend": dist.get_backend() if multi else None, "ranks_seen": int(ranks),
                "comm_selftest": "ok", "value": total_rays * steps / el / 1e6, "unit": "Mrays/s", "steps": steps, "ms_per_step": 1e3 * el / steps,
                "rays_per_gpu": n, "rounds": cnt["rounds"], "leaf_visits_per_ray": visits / total_rays, "records_routed_per_step": routed,
                "records_routed_fraction": routed / max(1.0, visits), "exchange_bytes_per_step_all_ranks": xbytes,
                "bytes_per_all_to_all_per_rank": xbytes / max(1.0, ranks * 2 * max(1, cnt["rounds"])),
                "resident_bvh_bytes_total": resident, "resident_mesh_bytes_total": mesh_total, "scene_build_s_rank0": build_s,
+               "scene": "built rank-locally: every rank makes geometry, BVH8s and SVDAGs of its own tiles only (scenes.CityTiles, accel.tiles_local_part / tiles_assemble)",
                "host_peak_rss_gb_rank0": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20}
     ctx.close()
     return rec
@@ -486,9 +514,21 @@ def main() -> int:
         if world > 1:
             dist.all_reduce(seen)
         elapsed, total = reduce_job(0.001 * (rank + 1), 1000, None)
+        # the sharded record's scene on a small city: own tiles only, bounds and DAGs exchanged, top level assembled on every rank
+        import pandora_amd as pa
+        tiles, tl, owner_by_tile, part, scene_s = sharded_scene(args, pa, dist, rank, world, 4, 16)
+        print("rank %d: scene_build_s %.2f (%d of %d tiles)" % (rank, scene_s, len(part["tiles"]), tiles.n_tiles), file=sys.stderr, flush=True)
+        tops = torch.tensor([float(np.asarray(tl.top.nodes, np.float64).sum()), float(len(part["tiles"])), float(tl.dags.words.size)], dtype=torch.float64)
+        all_tops = [torch.zeros_like(tops) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(all_tops, tops)
+        else:
+            all_tops = [tops]
         if rank == 0:
             emit({"metric": "Mrays/s incoherent diffuse rays", "value": total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "dry": True,
-                  "ranks_seen": [int(i) for i in torch.nonzero(seen).flatten().tolist()], "steps": args.steps, "warmup": args.warmup})
+                  "ranks_seen": [int(i) for i in torch.nonzero(seen).flatten().tolist()], "steps": args.steps, "warmup": args.warmup,
+                  "scene_tiles": tiles.n_tiles, "scene_tiles_built_per_rank": [int(t[1]) for t in all_tops],
+                  "scene_same_top_level_on_every_rank": bool(all(float(t[0]) == float(all_tops[0][0]) and float(t[2]) == float(all_tops[0][2]) for t in all_tops))})
         if world > 1:
             dist.destroy_process_group()
         # (test hook: a rank that fails after the line is out -- the launcher must hand its status on, tests/test_bench_launch.py)

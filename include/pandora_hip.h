@@ -118,6 +118,13 @@ void pgpu_host_svdags_free(pgpu_host_svdags*);
 int pgpu_svdag_expand(const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dag, uint32_t* grid_bits);
 int pgpu_voxelize(const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
     const uint32_t* prims, size_t n_prims, uint32_t resolution, float bounds_out[6], uint32_t* grid_bits);
+/* Adds `base` to every child offset of a word array that pgpu_build_svdags / pgpu_build_svdags_device produced (nodes back to
+ * back: a descriptor word, then one absolute offset per inner child, sparse_voxel_dag.h:40-78), so that arrays built apart --
+ * each rank of a sharded build makes the DAGs of its own batching points -- can be laid one behind the other and uploaded as
+ * one (the roots in the descriptors move by the same amount; the caller adds it). PGPU_ERR_INVALID when the words do not parse
+ * as such a sequence. The reference builds all DAGs in one process (compressDAGs, sparse_voxel_dag.cpp:135-226): what is lost
+ * here is only the sharing of equal subtrees ACROSS arrays. */
+int pgpu_svdag_rebase(uint32_t* words, size_t n_words, uint32_t base);
 
 /* ------------------------------------------------------------------ device context
  * One context per GPU, one process per GPU. Replaces the TaskGraph/LRU-cache plumbing the reference

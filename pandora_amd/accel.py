@@ -816,6 +816,93 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     return TwoLevelScene(groups, bvhs, top, dags, bounds)
 
 
+def svdags_concat(parts: list) -> "tuple[np.ndarray, list[np.ndarray]]":
+    """Word arrays of DAG sets built apart, laid one behind the other (pgpu_svdag_rebase): -> (words, per part its descriptors
+    with the roots moved along). parts: [(words uint32[], descs SVDAG_DESC_DTYPE[])]."""
+    L = capi.lib()
+    words, descs, base = [], [], 0
+    for w, d in parts:
+        w = np.ascontiguousarray(w, np.uint32).copy()
+        d = np.asarray(d, SVDAG_DESC_DTYPE).copy()
+        _check(L.pgpu_svdag_rebase(w.ctypes.data, w.size, base), what="pgpu_svdag_rebase failed")
+        d["root"] += np.uint32(base)
+        words.append(w)
+        descs.append(d)
+        base += int(w.size)
+    return (np.concatenate(words) if words else np.zeros(0, np.uint32)), descs
+
+
+def tiles_local_part(tiles, mine, svdag_res: int = 0, max_leaf: int = 4, svdag_device_ctx: "Context | None" = None) -> dict:
+    """One rank's share of a two-level build over a tiled scene (scenes.CityTiles: a tile is a batching point that can be made on
+    its own). Makes the geometry of the tiles marked in `mine` and nothing else, and from it the tiles' bounds, bottom-level BVH8s
+    and SVDAGs. -> {"tiles": ids, "pos", "idx": the local mesh (own tiles one behind the other), "groups": per own tile its
+    triangle ids in the local mesh, "bvhs": per own tile, "bounds": float32[k, 6], "dag_words", "dag_descs", "words_before"}.
+    "tiles", "bounds" and the three dag entries are what the other ranks need (tiles_assemble)."""
+    from . import scenes
+    ids = np.nonzero(np.asarray(mine, bool))[0]
+    meshes = [tiles.tile_mesh(int(t)) for t in ids]
+    groups, base = [], 0
+    for m in meshes:
+        groups.append(np.arange(base, base + m.n_tris, dtype=np.uint32))
+        base += m.n_tris
+    if meshes:
+        local = scenes.merge(meshes)
+        pos, idx = local.pos, local.idx
+    else:
+        pos, idx = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32)
+    bounds = np.empty((len(meshes), 6), np.float32)
+    for k, m in enumerate(meshes):
+        bounds[k, :3], bounds[k, 3:] = m.pos.min(axis=0), m.pos.max(axis=0)
+    del meshes
+    workers = max(1, min(host_threads(), len(groups)))
+    build = lambda g: build_bvh8(pos, idx, g, max_leaf)
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            bvhs = list(pool.map(build, groups))
+    else:
+        bvhs = [build(g) for g in groups]
+    part = {"tiles": ids, "pos": pos, "idx": idx, "groups": groups, "bvhs": bvhs, "bounds": bounds,
+            "dag_words": None, "dag_descs": None, "words_before": 0}
+    if svdag_res > 0 and groups:
+        d = build_svdags(pos, idx, groups, svdag_res, device_ctx=svdag_device_ctx)
+        part.update(dag_words=d.words, dag_descs=d.descs, words_before=d.words_before)
+    return part
+
+
+def tiles_assemble(n_tiles: int, shared: list, own: dict) -> TwoLevelScene:
+    """The whole two-level structure from every rank's shared entries (tiles_local_part; in rank order, the same list on every rank)
+    and this rank's own part: top level over all tiles' bounds, all SVDAGs, BVH8s and triangle groups of the own tiles only."""
+    bounds = np.empty((n_tiles, 6), np.float32)
+    seen = np.zeros(n_tiles, bool)
+    for sh in shared:
+        t = np.asarray(sh["tiles"], np.int64)
+        if seen[t].any():
+            raise ValueError("a tile was built by two ranks")
+        seen[t] = True
+        bounds[t] = sh["bounds"]
+    if not seen.all():
+        raise ValueError("tiles nobody built: %s" % np.nonzero(~seen)[0][:8])
+    dags = None
+    with_dags = [sh for sh in shared if sh["dag_words"] is not None]
+    if with_dags:
+        if sum(len(sh["tiles"]) for sh in with_dags) != n_tiles:
+            raise ValueError("SVDAGs for some tiles only")
+        words, descs = svdags_concat([(sh["dag_words"], sh["dag_descs"]) for sh in with_dags])
+        all_descs = np.zeros(n_tiles, SVDAG_DESC_DTYPE)
+        for sh, d in zip(with_dags, descs):
+            all_descs[np.asarray(sh["tiles"], np.int64)] = d
+        dags = HostSvdags(words, all_descs, int(sum(sh["words_before"] for sh in with_dags)))
+    groups = [np.zeros(0, np.uint32)] * n_tiles
+    bvhs = [None] * n_tiles
+    for k, t in enumerate(np.asarray(own["tiles"], np.int64)):
+        groups[int(t)], bvhs[int(t)] = own["groups"][k], own["bvhs"][k]
+    return TwoLevelScene(groups, bvhs, build_top_bvh4(bounds), dags, bounds)
+
+
+TILE_SHARED_KEYS = ("tiles", "bounds", "dag_words", "dag_descs", "words_before")
+
+
 @dataclass
 class InstancedTwoLevelScene:
     """A scene graph with plain triangles and instanced prototypes, cut into batching points the way the reference's builder

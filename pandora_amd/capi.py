@@ -95,6 +95,7 @@ SYMBOLS = {
     "pgpu_host_svdags_words_before_compression": (C.c_size_t, [C.c_void_p]),
     "pgpu_host_svdags_free": (None, [C.c_void_p]),
     "pgpu_svdag_expand": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(SvdagDesc), C.c_void_p]),
+    "pgpu_svdag_rebase": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32]),
     "pgpu_voxelize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pgpu_bvh8_serialize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pgpu_bvh8_deserialize": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),

@@ -360,6 +360,37 @@ int pgpu_voxelize(const float* positions, size_t n_vertices, const uint32_t* ind
     return PGPU_OK;
 }
 
+int pgpu_svdag_rebase(uint32_t* words, size_t n_words, uint32_t base)
+{
+    if (!words && n_words)
+        return PGPU_ERR_INVALID;
+    if (uint64_t(n_words) + base > 0xFFFFFFFFull)
+        return PGPU_ERR_INVALID;
+    // first pass: the array must be a whole number of nodes whose offsets stay inside it (nothing is changed on failure)
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t at = 0;
+        while (at < n_words) {
+            const uint32_t d = words[at];
+            if (d >> 16)
+                return PGPU_ERR_INVALID;
+            const uint32_t inner = ((d >> 8) & 0xFFu) & ~(d & 0xFFu);
+            const size_t k = size_t(__builtin_popcount(inner));
+            if (at + 1 + k > n_words)
+                return PGPU_ERR_INVALID;
+            for (size_t i = 1; i <= k; ++i) {
+                if (pass == 0) {
+                    if (words[at + i] >= n_words)
+                        return PGPU_ERR_INVALID;
+                } else {
+                    words[at + i] += base;
+                }
+            }
+            at += 1 + k;
+        }
+    }
+    return PGPU_OK;
+}
+
 int pgpu_svdag_expand(const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dag, uint32_t* grid_bits)
 {
     if (!words || !dag || !grid_bits || dag->root >= n_words || !powerOfTwo(dag->resolution))

@@ -226,34 +226,129 @@ def g_atrium(target_tris: int = 262_144, seed: int = 7) -> Mesh:
     return merge(parts)
 
 
+def _city_block_params(n_blocks_side: int, seed: int):
+    """The random draws of g_city, block by block in its order: per block 5 boxes (centre offset, half size) and 5 spheres
+    (centre offset, height, radius). A few numbers per block -- every rank of a sharded build draws all of them and makes
+    geometry only for its own blocks."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_blocks_side * n_blocks_side):
+        boxes = [(rng.uniform((-6, 0, -6), (6, 0, 6)), rng.uniform(1.0, 3.0, 3)) for _ in range(5)]
+        spheres = []
+        for _ in range(5):
+            c = rng.uniform((-8, 0, -8), (8, 0, 8))
+            y = 3.0 + rng.uniform(0, 6)
+            spheres.append((c, y, rng.uniform(0.6, 1.6)))
+        out.append((boxes, spheres))
+    return out
+
+
+def _city_block_parts(params, bx: int, bz: int, sub: int, lvl: int):
+    boxes, spheres = params
+    cx, cz = 10.0 + 20.0 * bx, 10.0 + 20.0 * bz
+    parts = [box((cx + c[0] - s[0], 1.5, cz + c[2] - s[2]), (cx + c[0] + s[0], 1.5 + 4 * s[1], cz + c[2] + s[2]), sub) for c, s in boxes]
+    parts += [icosphere((cx + c[0], y, cz + c[2]), r, lvl) for c, y, r in spheres]
+    return parts
+
+
+def _city_shape(n_blocks_side: int, tris_per_block: int):
+    tn = max(16, int((tris_per_block * n_blocks_side * n_blocks_side / 8) ** 0.5))  # terrain cells per side
+    sub = max(1, int(round((tris_per_block / 10 / 12) ** 0.5)))
+    lvl = 3 if tris_per_block < 20000 else (4 if tris_per_block < 80000 else 5)
+    return tn, sub, lvl
+
+
 def g_city(n_blocks_side: int, tris_per_block: int, seed: int = 11) -> Mesh:
     """Large stand-in (San-Miguel / Moana class): a terrain heightfield plus a grid of detailed blocks.
 
     Spatially well separated clusters, so a primitives-per-batching-point cut yields meaningful
     batching points.
     """
-    parts = []
     size = 20.0 * n_blocks_side
+    tn, sub, lvl = _city_shape(n_blocks_side, tris_per_block)
 
     def terrain(s, t):
         return np.stack([np.zeros_like(s), 1.5 * _noise(s, t, seed, 5), np.zeros_like(s)], 1)
 
-    tn = max(16, int((tris_per_block * n_blocks_side * n_blocks_side / 8) ** 0.5))
-    parts.append(grid_patch((0, 0, 0), (size, 0, 0), (0, 0, size), tn, tn, displace=terrain))
-    rng = np.random.default_rng(seed)
-    sub = max(1, int(round((tris_per_block / 10 / 12) ** 0.5)))
+    parts = [grid_patch((0, 0, 0), (size, 0, 0), (0, 0, size), tn, tn, displace=terrain)]
+    params = _city_block_params(n_blocks_side, seed)
     for bx in range(n_blocks_side):
         for bz in range(n_blocks_side):
-            cx, cz = 10.0 + 20.0 * bx, 10.0 + 20.0 * bz
-            for _ in range(5):
-                c = rng.uniform((-6, 0, -6), (6, 0, 6))
-                s = rng.uniform(1.0, 3.0, 3)
-                parts.append(box((cx + c[0] - s[0], 1.5, cz + c[2] - s[2]), (cx + c[0] + s[0], 1.5 + 4 * s[1], cz + c[2] + s[2]), sub))
-            lvl = 3 if tris_per_block < 20000 else (4 if tris_per_block < 80000 else 5)
-            for _ in range(5):
-                c = rng.uniform((-8, 0, -8), (8, 0, 8))
-                parts.append(icosphere((cx + c[0], 3.0 + rng.uniform(0, 6), cz + c[2]), rng.uniform(0.6, 1.6), lvl))
+            parts += _city_block_parts(params[bx * n_blocks_side + bz], bx, bz, sub, lvl)
     return merge(parts)
+
+
+class CityTiles:
+    """g_city as tiles that can be made one at a time: a tile is `blocks_per_tile` blocks along x by one block along z, with the
+    terrain cells whose centre lies over it. The union of all tiles is g_city's triangles (same vertices bit for bit; vertices on
+    tile borders are repeated). For builds in which every rank makes only the geometry of its own batching points: a tile IS a
+    batching point, its triangle count (`weights`) is known without making it."""
+
+    def __init__(self, n_blocks_side: int, tris_per_block: int, seed: int = 11, blocks_per_tile: int = 2):
+        self.n, self.seed, self.bpt = int(n_blocks_side), int(seed), int(blocks_per_tile)
+        self.size = 20.0 * self.n
+        self.tn, self.sub, self.lvl = _city_shape(self.n, tris_per_block)
+        self.params = _city_block_params(self.n, seed)
+        self.tiles_x = (self.n + self.bpt - 1) // self.bpt
+        self.n_tiles = self.tiles_x * self.n
+        self._lin = np.linspace(0, 1, self.tn + 1, dtype=np.float32)  # (grid_patch's parameter values)
+
+    def _cells(self, b0: int, b1: int):
+        """terrain cells i with centre over blocks [b0, b1): (2 i + 1) n < 2 tn b, in integers"""
+        first = lambda b: min(self.tn, max(0, -((self.n - 2 * self.tn * b) // (2 * self.n))))
+        return first(b0), first(b1)
+
+    def tile_blocks(self, t: int):
+        tx, bz = divmod(int(t), self.n)
+        return [(bx, bz) for bx in range(tx * self.bpt, min(self.n, (tx + 1) * self.bpt))]
+
+    def tile_cell(self, t: int):
+        """(x, z) position of the tile in the tile grid (for space-filling orders)"""
+        return divmod(int(t), self.n)
+
+    def weights(self) -> np.ndarray:
+        w = np.zeros(self.n_tiles, np.int64)
+        per_block = 5 * 12 * self.sub * self.sub + 5 * 20 * 4 ** self.lvl
+        for t in range(self.n_tiles):
+            blocks = self.tile_blocks(t)
+            i0, i1 = self._cells(blocks[0][0], blocks[-1][0] + 1)
+            j0, j1 = self._cells(blocks[0][1], blocks[0][1] + 1)
+            w[t] = per_block * len(blocks) + 2 * (i1 - i0) * (j1 - j0)
+        return w
+
+    def tile_mesh(self, t: int) -> Mesh:
+        blocks = self.tile_blocks(t)
+        i0, i1 = self._cells(blocks[0][0], blocks[-1][0] + 1)
+        j0, j1 = self._cells(blocks[0][1], blocks[0][1] + 1)
+        parts = []
+        if i1 > i0 and j1 > j0:  # the terrain cells, with grid_patch's arithmetic on the stretch of its parameter grid
+            s, u = np.meshgrid(self._lin[i0:i1 + 1], self._lin[j0:j1 + 1], indexing="ij")
+            s, u = s.ravel(), u.ravel()
+            du, dv = np.asarray((self.size, 0, 0), np.float32), np.asarray((0, 0, self.size), np.float32)
+            p = np.zeros(3, np.float32)[None, :] + s[:, None] * du[None, :] + u[:, None] * dv[None, :]
+            p = p + np.stack([np.zeros_like(s), 1.5 * _noise(s, u, self.seed, 5), np.zeros_like(s)], 1).astype(np.float32)
+            nv = j1 - j0
+            i, j = np.meshgrid(np.arange(i1 - i0), np.arange(nv), indexing="ij")
+            a = (i * (nv + 1) + j).ravel()
+            b = a + (nv + 1)
+            parts.append(Mesh(p, np.concatenate([np.stack([a, b, b + 1], 1), np.stack([a, b + 1, a + 1], 1)])))
+        for bx, bz in blocks:
+            parts += _city_block_parts(self.params[bx * self.n + bz], bx, bz, self.sub, self.lvl)
+        return merge(parts)
+
+    def normals_of(self, tile: np.ndarray, obj: np.ndarray) -> np.ndarray:
+        """Geometric normals (not normalised) of hits given as (tile, triangle of the tile); makes each tile that was hit, once."""
+        tile, obj = np.asarray(tile, np.int64), np.asarray(obj, np.int64)
+        out = np.zeros((tile.size, 3), np.float64)
+        order = np.argsort(tile, kind="stable")
+        cuts = np.nonzero(np.diff(tile[order]))[0] + 1
+        for run in np.split(order, cuts):
+            if run.size == 0:
+                continue
+            m = self.tile_mesh(int(tile[run[0]]))
+            v = m.pos[m.idx[obj[run]]].astype(np.float64)
+            out[run] = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+        return out
 
 
 def tree_prototype(seed: int, detail: int = 2) -> Mesh:

@@ -25,6 +25,9 @@ def test_plain_start_spawns_the_ranks():
     assert p.returncode == 0, p.stderr[-2000:]
     line = _json_line(p.stdout)
     assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["dry"] is True and line["steps"] == 3
+    # the sharded record's scene, built rank-locally on a small city: half the tiles each, the same top level and DAG array on both
+    assert line["scene_tiles_built_per_rank"] == [line["scene_tiles"] // 2] * 2 and line["scene_same_top_level_on_every_rank"] is True
+    assert "rank 0: scene_build_s" in p.stderr and "rank 1: scene_build_s" in p.stderr
     # slowest rank's time (2 ms) over the rays of both ranks
     assert abs(line["value"] - 2000 / 0.002 / 1e6) < 1e-6
 

@@ -231,3 +231,37 @@ def test_collapsed_construction_against_the_greedy_one(monkeypatch):
     assert differ <= 2e-4 * rays.shape[1], differ
     assert res["dp"][0] < 0.75 * res["greedy"][0]
     assert res["dp"][2] < res["greedy"][2]
+
+
+def test_ranks_partial_builds_of_a_tiled_city_add_up_to_the_single_rank_build():
+    """bench.py's sharded scene: every rank makes the geometry, BVH8s and SVDAGs of its own tiles only (tiles_local_part), the
+    ranks exchange bounds and DAGs, and each assembles the whole two-level structure (tiles_assemble). Two ranks' results against
+    one rank that builds everything: same top level, same bounds, same BVH8 bytes per tile, same voxels per DAG."""
+    tiles = pa.scenes.CityTiles(4, 2500)
+    whole = pa.scenes.g_city(4, 2500)
+    assert sum(int(w) for w in tiles.weights()) == whole.n_tris
+    n = tiles.n_tiles
+    one = pa.accel.tiles_local_part(tiles, np.ones(n, bool), svdag_res=16)
+    ref = pa.accel.tiles_assemble(n, [{k: one[k] for k in pa.accel.TILE_SHARED_KEYS}], one)
+    owner = np.arange(n) % 2
+    parts = [pa.accel.tiles_local_part(tiles, owner == r, svdag_res=16) for r in range(2)]
+    shared = [{k: p[k] for k in pa.accel.TILE_SHARED_KEYS} for p in parts]
+    for r in range(2):
+        tl = pa.accel.tiles_assemble(n, shared, parts[r])
+        assert np.array_equal(tl.leaf_bounds, ref.leaf_bounds)
+        assert np.array_equal(tl.top.nodes.view(np.uint32), ref.top.nodes.view(np.uint32)) and np.array_equal(tl.top.leaf_order, ref.top.leaf_order)
+        for t in range(n):
+            if owner[t] == r:
+                assert pa.accel.bvh8_to_bytes(tl.bvhs[t]) == pa.accel.bvh8_to_bytes(ref.bvhs[t]), t
+                assert tl.groups[t].size == ref.groups[t].size == tiles.weights()[t]
+            else:
+                assert tl.bvhs[t] is None and tl.groups[t].size == 0
+            for k in ("bounds_min", "inv_extent", "resolution"):
+                assert np.array_equal(tl.dags.descs[t][k], ref.dags.descs[t][k])
+            assert np.array_equal(pa.accel.svdag_expand(tl.dags.words, tl.dags.descs[t]), pa.accel.svdag_expand(ref.dags.words, ref.dags.descs[t])), t
+    # the local meshes, one behind the other in tile order, are the single-rank mesh
+    m0, m1 = parts[0], parts[1]
+    assert m0["idx"].shape[0] + m1["idx"].shape[0] == one["idx"].shape[0] == whole.n_tris
+    with pytest.raises(pa.accel.PandoraError):
+        bad = np.array([0x0300, 5], np.uint32)  # a node with two inner children and one offset word
+        pa.accel._check(pa.capi.lib().pgpu_svdag_rebase(bad.ctypes.data, bad.size, 4), what="rebase")

@@ -224,3 +224,34 @@ def test_svdag_policy_skips_the_test_for_resident_points(two_level):
     assert np.array_equal(_bits(again["visits"]), _bits(ref["visits"]))
     if tl.dags is not None:
         assert cnt2["svdag_tests"] > 0
+
+
+def test_tiled_city_assembled_from_two_ranks_parts_matches_oracle():
+    """bench.py's rank-local scene build: the top level from the tiles' exchanged bounds and the SVDAG array laid together from
+    two ranks' arrays (pgpu_svdag_rebase), over the geometry and BVH8s of all tiles -- traced on the GPU and by the oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    tiles = pa.scenes.CityTiles(4, 2500)
+    n = tiles.n_tiles
+    one = pa.accel.tiles_local_part(tiles, np.ones(n, bool), svdag_res=32)
+    parts = [pa.accel.tiles_local_part(tiles, np.arange(n) % 2 == r, svdag_res=32) for r in range(2)]
+    tl = pa.accel.tiles_assemble(n, [{k: p[k] for k in pa.accel.TILE_SHARED_KEYS} for p in parts], one)
+    mesh = pa.scenes.Mesh(one["pos"], one["idx"])
+    ctx = pa.accel.Context(0)
+    try:
+        tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+        orc = ob.scene_from_two_level(tl, mesh)
+        lo, hi = mesh.bounds()
+        rays = np.ascontiguousarray(np.concatenate([
+            pa.scenes.random_rays(lo, hi + (0, 10, 0), 20000, seed=21),
+            pa.scenes.random_rays(lo - 50, hi + 50, 20000, seed=22, toward=(lo, hi))], axis=1))
+        got, cnt = ctx.trace(rays)
+        want = orc.trace(rays, lanes=3)
+        for k in ("t", "obj", "leaf", "u", "v", "visits"):
+            assert np.array_equal(_bits(got[k]), _bits(want[k])), k
+        for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
+            assert cnt[k] == want["counters"][k], k
+        assert cnt["svdag_culled"] > 0 and (got["obj"].view(np.uint32) != 0xFFFFFFFF).mean() > 0.2
+    finally:
+        ctx.close()
