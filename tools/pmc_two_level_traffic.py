@@ -1,7 +1,8 @@
 """Per-step memory-side traffic and issue figures of the two-level round loop from rocprofv3 --pmc passes over
 `bench.py --config two-level` (tools/pmc_passes.sh <tag> --config two-level): sums the dispatches of the LAST trace of each
-run (everything from its last initStateKernel on), per kernel.
-Usage: python tools/pmc_two_level_traffic.py <dir with p1..pN pass directories> <out.json> [rays]"""
+run, per kernel: everything from the first initStateKernel of that trace on -- a trace of a large batch runs as PARTS batches side by
+side (pgpu_set_batch_parts, default 2), each with an initStateKernel of its own.
+Usage: [PARTS=2] python tools/pmc_two_level_traffic.py <dir with p1..pN pass directories> <out.json> [rays]"""
 import csv, glob, json, os, sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,8 @@ def last_step(pass_dir):
     out = {}
     for counter in sorted({r["Counter_Name"] for r in rows}):
         rs = sorted((r for r in rows if r["Counter_Name"] == counter), key=lambda r: int(r["Dispatch_Id"]))
-        start = max(i for i, r in enumerate(rs) if "initStateKernel" in r["Kernel_Name"])
+        inits = [i for i, r in enumerate(rs) if "initStateKernel" in r["Kernel_Name"]]
+        start = inits[-min(len(inits), int(os.environ.get("PARTS", "2")))]
         per = {}
         for r in rs[start:]:
             k = r["Kernel_Name"]
