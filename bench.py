@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--force-sharded", action="store_true", help="N = 1: run the sharded record too (one rank owns every batching point; rehearsal of the N > 1 path)")
     ap.add_argument("--no-two-level", action="store_true", help="N = 1, --config single: skip the `two_level` sub-record (configs[2], timed after the headline)")
     ap.add_argument("--two-level-steps", type=int, default=10, help="timed steps of the `two_level` sub-record")
+    ap.add_argument("--top-variant", type=int, default=0, help="two-level: pgpu_set_top_variant (0 automatic, 1 lockstep waves, 2 independent lanes, 3 lockstep first episode then lanes)")
+    ap.add_argument("--batch-parts", type=int, default=0, help="two-level: pgpu_set_batch_parts (0 = the library's default: two parts from 2^21 rays on; 1 = the batch as one)")
     ap.add_argument("--dry", action="store_true", help="no GPU: the ranks only meet (gloo) and reduce made-up figures; checks the launch path")
     return ap.parse_args()
 
@@ -240,6 +242,8 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
     if args.svdag_defer:
         ctx.set_svdag_defer(args.svdag_defer, 2)
     ctx.set_svdag_policy(1 if args.svdag_policy == "nonresident" else 0)
+    ctx.set_top_variant(args.top_variant)
+    ctx.set_batch_parts(args.batch_parts)
     stream = torch.cuda.current_stream().cuda_stream
     prim = city_camera(pa, args.city_blocks, args.side, 891379 + 7919 * rank)
     first, _ = ctx.trace(torch.from_numpy(prim).to(dev), stream=stream)
