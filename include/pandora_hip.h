@@ -188,7 +188,7 @@ int pgpu_stage_bvh8_instanced(pgpu_ctx*, const void* nodes256, size_t n_nodes, c
  * (pgpu_set_leaf_copy(ctx, 1): one hipMemcpyAsync per image instead), on a copy stream, overlapped with the traversal of
  * the previous group. Rays wait: like the reference, which drains its fullest queue first and lets the others fill
  * (task_graph.cpp:19-56), a round loads an image that is not in the cache only once its batching point holds one ray per
- * `image_bytes_per_ray` bytes of image (pgpu_set_leaf_hold; default 256, 0 = every point with a ray is loaded every round);
+ * `image_bytes_per_ray` bytes of image (pgpu_set_leaf_hold; default 128, 0 = every point with a ray is loaded every round);
  * the rays of the other points stay parked and join the next round's queues (when no point qualifies, the points with the
  * most rays per byte are taken, one cache-full of them). Results do not depend on any of this; pgpu_counters.rounds does.
  * pgpu_set_leaf_cache sets the HBM budget of the cache in bytes (0 = room for every staged BVH); it must
@@ -202,6 +202,15 @@ int pgpu_stage_bvh8(pgpu_ctx*, const void* nodes256, size_t n_nodes, const uint3
 int pgpu_set_leaf_cache(pgpu_ctx*, size_t bytes);
 int pgpu_set_leaf_copy(pgpu_ctx*, int mode);
 int pgpu_set_leaf_hold(pgpu_ctx*, uint32_t image_bytes_per_ray);
+/* Queues that will not fill: once as many rays wait as still move (or nothing moves at all) the waiting queues are flushed, and a
+ * flushed queue with fewer rays than one per `image_bytes_per_ray` bytes of its image is not loaded at all -- its rays traverse
+ * the image where it lies, in pinned host memory, through the same kernel: a visit pulls the nodes and records it touches over
+ * PCIe (through the L2, so rays of one launch share them), loading the image for a handful of rays moves all of it and orders
+ * copies and launches one behind the other. Default 128 = the default of pgpu_set_leaf_hold: every flushed queue is traced in
+ * place, images are loaded only for queues that reach the hold threshold. 0 = every flushed queue is loaded, fullest first, one
+ * cache-full per round. The reference has no counterpart (its leaves are loaded whole from disk, offline_bvh_cache.cpp:127-148).
+ * Same results. */
+int pgpu_set_leaf_in_place(pgpu_ctx*, uint32_t image_bytes_per_ray);
 
 /* Shared SVDAG array + one descriptor per DAG (SparseVoxelDAG members, sparse_voxel_dag.h:70-78). */
 int pgpu_upload_svdags(pgpu_ctx*, const uint32_t* words, size_t n_words, const pgpu_svdag_desc* dags, size_t n_dags);

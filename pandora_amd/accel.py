@@ -434,6 +434,11 @@ class Context:
         bytes of image; until then the point's rays stay parked (0 = never wait). Default 256."""
         _check(self._L.pgpu_set_leaf_hold(self._h, int(image_bytes_per_ray)), self._h)
 
+    def set_leaf_in_place(self, image_bytes_per_ray: int):
+        """Flushed queues with fewer rays than one per this many bytes of image are traced in pinned host memory instead of being
+        loaded (pgpu_set_leaf_in_place; default 128, 0 = never). Same results."""
+        _check(self._L.pgpu_set_leaf_in_place(self._h, int(image_bytes_per_ray)), self._h)
+
     def set_leaf_copy(self, mode: int):
         """How staged images reach the HBM cache: 0 = one gather kernel per launch group (default), 1 = one hipMemcpyAsync per image."""
         _check(self._L.pgpu_set_leaf_copy(self._h, int(mode)), self._h)

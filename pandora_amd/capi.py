@@ -114,6 +114,7 @@ SYMBOLS = {
     "pgpu_set_leaf_cache": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pgpu_set_leaf_copy": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_set_leaf_hold": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "pgpu_set_leaf_in_place": (C.c_int, [C.c_void_p, C.c_uint32]),
     "pgpu_set_svdag_policy": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_upload_svdags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "pgpu_upload_top_bvh4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t]),

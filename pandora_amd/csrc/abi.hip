@@ -287,6 +287,8 @@ int pgpu_init(int device_id, pgpu_ctx** out)
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = std::getenv("PANDORA_LEAF_DRAIN")) // (tuning knob of the streamed loop's queue policy, top_abi.hip; results do not depend on it)
         c->leafDrainRatio = float(std::atof(e));
+    if (const char* e = std::getenv("PANDORA_LEAF_INPLACE"))
+        c->leafInPlaceBytesPerRay = uint32_t(std::atol(e));
     if (const char* e = std::getenv("PANDORA_LEAF_PREFETCH"))
         c->leafPrefetchBytesPerRay = float(std::atof(e));
     if (initStaticScratch(c) != PGPU_OK) {
@@ -660,6 +662,14 @@ int pgpu_set_leaf_hold(pgpu_ctx* c, uint32_t image_bytes_per_ray)
     if (!c)
         return PGPU_ERR_INVALID;
     c->leafHoldBytesPerRay = image_bytes_per_ray;
+    return PGPU_OK;
+}
+
+int pgpu_set_leaf_in_place(pgpu_ctx* c, uint32_t image_bytes_per_ray)
+{
+    if (!c)
+        return PGPU_ERR_INVALID;
+    c->leafInPlaceBytesPerRay = image_bytes_per_ray;
     return PGPU_OK;
 }
 

@@ -101,9 +101,10 @@ struct pgpu_ctx {
     size_t cacheBytes = 0, ringWrite = 0;
     std::deque<uint32_t> ring;
     uint64_t groupClock = 0;
-    uint32_t leafHoldBytesPerRay = 256; // pgpu_set_leaf_hold: an image that is not in the cache is loaded once its point holds a ray per this many bytes (0: always)
+    uint32_t leafHoldBytesPerRay = 128; // pgpu_set_leaf_hold: an image that is not in the cache is loaded once its point holds a ray per this many bytes (0: always)
+    uint32_t leafInPlaceBytesPerRay = 128; // pgpu_set_leaf_in_place: flushed queues with fewer rays than one per this many bytes of image are traced in host memory (0: never)
     float leafPrefetchBytesPerRay = 0.0f; // waiting points are loaded early up to this many bytes of image per moving ray and round (PANDORA_LEAF_PREFETCH)
-    float leafDrainRatio = 4.0f; // waiting queues are flushed as well once they hold more than this many times the rays that still move (PANDORA_LEAF_DRAIN)
+    float leafDrainRatio = 1.0f; // waiting queues are flushed as well once they hold more than this many times the rays that still move (PANDORA_LEAF_DRAIN)
     int leafCopyMode = 0;   // pgpu_set_leaf_copy: 0 = one gather kernel per launch group reads the pinned images, 1 = one hipMemcpyAsync per image
     void* copyTableHost = nullptr; // pinned: the gather kernel's segments and the BVH-table entries that changed, one run per launch group
     void* copyTableDev = nullptr;
@@ -169,6 +170,10 @@ int prepareLeafCache(pgpu_ctx* c);
 // (arrivalsOnly: every launch sees, of the BVHs batching points name, only the images its own group brought in)
 int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& visitOrder, const uint32_t* leafStart,
     const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream, bool arrivalsOnly = false);
+// the rays of the given batching points (staged, not in the cache) through their images where they lie in pinned host memory: one
+// launch over the stretch of the list the points span, through a view of the BVH table in which only they are visible
+int traceLeavesInPlace(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& points, const uint32_t* leafStart,
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream);
 // route_abi.hip. instRows: closest-hit result rows have five values (the instance of the hit last), see launchPackResults
 // (cursor / spill: for a launch that runs next to another bottom-level launch of the same context; default = the context's)
 int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows = false,

@@ -311,6 +311,64 @@ int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint3
     return PGPU_OK;
 }
 
+int traceLeavesInPlace(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& points, const uint32_t* leafStart,
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream)
+{
+    if (points.empty())
+        return PGPU_OK;
+    if (!c->tableView.ptr)
+        return fail(c, PGPU_ERR_INVALID, "leaf cache: no table view (internal)");
+    const TraceRange range_("round: bottom level, sparse batching points traced in host memory");
+    if (uint32_t(c->groupClock + 1) == 0u)
+        ++c->groupClock;
+    const uint64_t group = ++c->groupClock; // (a group nothing arrives with: the view hides every BVH a batching point names)
+    const size_t n = points.size();
+    if (c->copyTableNext + n > c->copyTableCap) { // (the table is reused from its start: everything that read it must be done)
+        HIP_TRY(c, hipStreamSynchronize(c->copyStream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        c->copyTableNext = 0;
+    }
+    unsigned char* const host = static_cast<unsigned char*>(c->copyTableHost) + c->copyTableNext * 64;
+    unsigned char* const dev = static_cast<unsigned char*>(c->copyTableDev) + c->copyTableNext * 64;
+    c->copyTableNext += n;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t l = points[i];
+        const uint32_t id = c->topLeavesHost[l].bvh;
+        if (id >= c->staged.size() || !c->staged[id].host || c->staged[id].resident)
+            return fail(c, PGPU_ERR_INVALID, "leaf cache: a point traced in place must be staged and not resident (internal)");
+        const StagedBvh& s = c->staged[id];
+        LeafTableFix fix {};
+        fix.entry = c->bvhs[id];
+        fix.entry.nodes = s.host; // (pinned memory: the device reads it at the same address, as the gather kernel does)
+        fix.entry.tris = s.host + s.nodeBytes;
+        fix.entry.inst = s.instBytes ? s.host + s.nodeBytes + s.triBytes : nullptr;
+        fix.id = id;
+        fix.group = 0u;
+        std::memcpy(host + i * 64, &fix, sizeof(fix));
+        lo = std::min(lo, leafStart[l]);
+        hi = std::max(hi, leafStart[l] + leafCount[l]);
+    }
+    HIP_TRY(c, hipMemcpyAsync(dev, host, n * 64, hipMemcpyHostToDevice, stream));
+    Bvh8Dev* const view = static_cast<Bvh8Dev*>(c->tableView.ptr);
+    const uint32_t* const leafFlag = reinterpret_cast<const uint32_t*>(static_cast<unsigned char*>(c->tableView.ptr) + c->bvhTableCap * sizeof(Bvh8Dev));
+    HIP_TRY(c, launchLeafTableView(c->bvhTable, leafFlag, leafFlag + c->bvhTableCap, uint32_t(group), view, uint32_t(c->bvhs.size()), stream));
+    HIP_TRY(c, launchLeafTableFix(dev, uint32_t(n), view, stream, nullptr));
+    HIP_TRY(c, hipMemsetAsync(cursor, 0, 256, stream));
+    ba.cursor = cursor;
+    ba.bvhs = view;
+    ba.work_ray += lo;
+    ba.work_bvh += lo;
+    ba.work_tag += lo;
+    ba.n_work = hi - lo;
+    uint32_t blocks = 1;
+    const int rc = planBvh8Launch(c, deepest, hi - lo, ba, &blocks, spill);
+    if (rc != PGPU_OK)
+        return rc;
+    HIP_TRY(c, launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, stream));
+    return PGPU_OK;
+}
+
 } // namespace pandora_hip
 
 // one record per batching point with its DAG's descriptor inlined (LeafDagDev); needs the leaves, and the DAGs they name
@@ -759,7 +817,7 @@ static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
     rc = ensureLeafCache(c);
     if (rc != PGPU_OK)
         return rc;
-    std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder;
+    std::vector<uint32_t> hLeafCount, hLeafStart, visitOrder, inPlace;
     std::vector<uint8_t> traced, inCache;
     uint32_t* dHeldRay[2] = { nullptr, nullptr };
     uint32_t* dHeldLeaf[2] = { nullptr, nullptr };
@@ -813,10 +871,11 @@ static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
     // streamed scenes: a round's bottom level runs in two passes (see the loop below) when the kernel can take its list length from
     // device memory; pgpu_set_round_lookahead(ctx, 0) restores the single pass behind the host's decision
     const bool earlyPass = streaming && pairLists && c->roundLookahead;
-    if (earlyPass) {
+    if (earlyPass)
         for (hipEvent_t& e : c->roundEv)
             if (!e)
                 HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (streaming) { // (the second pass of a round and the launches that trace in host memory go through a view of the BVH table)
         rc = prepareTableView(c);
         if (rc == PGPU_OK)
             rc = fillTableView(c, stream);
@@ -1082,6 +1141,7 @@ static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
             // points early, leafPrefetchBytesPerRay bytes of image per moving ray, fullest queues first)
             const size_t prefetchBudget = size_t(double(c->leafPrefetchBytesPerRay) * double(raysOn));
             const bool drain = nTraced == 0 || double(raysWaiting) > c->leafDrainRatio * double(raysOn);
+            inPlace.clear();
             if (nWaiting && (drain || loadBytes < prefetchBudget)) {
                 const size_t limit = drain ? c->cacheBytes : std::min(c->cacheBytes, prefetchBudget);
                 visitOrder.clear();
@@ -1092,28 +1152,43 @@ static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
                     const double rx = double(hLeafCount[x]) / double(stagedImage(x)->imageBytes()), ry = double(hLeafCount[y]) / double(stagedImage(y)->imageBytes());
                     return rx > ry || (rx == ry && x < y);
                 });
+                // A flushed queue with only a few rays is not worth its image: those rays traverse the image where it lies, in pinned
+                // host memory (a visit reads a few KB over PCIe, the image is hundreds). In the tail of a trace that is most queues
+                // -- 77 % of the benchmark landscape's loads served 0.15 % of its visits -- and since tracing in place has no cache
+                // to fit, ALL of them go at once instead of one cache-full per round.
                 for (uint32_t l : visitOrder) {
                     const size_t b = alignUp(stagedImage(l)->imageBytes());
-                    if (nTraced && loadBytes + b > limit)
-                        break;
-                    loadBytes += b;
+                    const bool sparse = drain && c->leafInPlaceBytesPerRay != 0u && uint64_t(hLeafCount[l]) * c->leafInPlaceBytesPerRay < stagedImage(l)->imageBytes();
+                    if (sparse) {
+                        inPlace.push_back(l);
+                    } else {
+                        if (nTraced && loadBytes + b > limit)
+                            continue; // (fuller queues first; the sparse ones behind it in the order still go in place)
+                        loadBytes += b;
+                    }
                     traced[l] = 1;
                     ++nTraced;
                     --nWaiting;
                 }
+                std::sort(inPlace.begin(), inPlace.end());
             }
             visitOrder.clear();
             uint64_t tracedRays = 0;
-            for (size_t l = 0; l < nl; ++l)
-                if (traced[l]) {
-                    if (!inCache[l])
-                        visitOrder.push_back(uint32_t(l)); // second pass: the points whose image has to come in first
-                    tracedRays += hLeafCount[l];
-                }
+            {
+                size_t ip = 0;
+                for (size_t l = 0; l < nl; ++l)
+                    if (traced[l]) {
+                        const bool here = ip < inPlace.size() && inPlace[ip] == l;
+                        ip += here ? 1 : 0;
+                        if (!inCache[l] && !here)
+                            visitOrder.push_back(uint32_t(l)); // second pass: the points whose image has to come in first
+                        tracedRays += hLeafCount[l];
+                    }
+            }
             leafVisits += tracedRays;
             if (std::getenv("PANDORA_TRACE_ROUNDS"))
-                std::fprintf(stderr, "round %llu: parked %u (active %u held %u) traced rays %llu, points traced %zu (second pass %zu) waiting %zu\n",
-                    (unsigned long long)rounds, parked, nActive, nHeld, (unsigned long long)tracedRays, nTraced, visitOrder.size(), nWaiting);
+                std::fprintf(stderr, "round %llu: parked %u (active %u held %u) traced rays %llu, points traced %zu (second pass %zu, in host memory %zu) waiting %zu\n",
+                    (unsigned long long)rounds, parked, nActive, nHeld, (unsigned long long)tracedRays, nTraced, visitOrder.size(), inPlace.size(), nWaiting);
             if (nWaiting) { // split the binned list: the traced points' rays go on, the others wait (one small kernel; skipped when nothing waits)
                 uint32_t* const hHeldCount = c->leafHostBuf + nl; // (pinned; read by the copies queued at the end of the round)
                 uint32_t* const hSplitDst = c->leafHostBuf + 2 * nl;
@@ -1141,6 +1216,8 @@ static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
             ba.work_tag = dWorkLeaf;
             ba.chunk = c->chunk;
             rc = traceLeafGroups(c, ba, kind, tri_mode, deepest, visitOrder, hLeafStart.data(), hLeafCount.data(), c->cursor, nullptr, stream, firstPassRan);
+            if (rc == PGPU_OK)
+                rc = traceLeavesInPlace(c, ba, kind, tri_mode, deepest, inPlace, hLeafStart.data(), hLeafCount.data(), c->cursor, nullptr, stream);
             if (rc != PGPU_OK)
                 return rc;
             ba.bvhs = c->bvhTable;

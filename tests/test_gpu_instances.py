@@ -73,12 +73,15 @@ def test_two_level_instanced_landscape_resident_and_streamed(svdag):
     want = {k: scene.trace(rays, any_hit=(k == pa.capi.ANY), threads=8) for k in (pa.capi.CLOSEST, pa.capi.ANY)}
     assert (want[pa.capi.CLOSEST]["inst"] != ob.MISS).mean() > 0.03
     slot = max(b.n_nodes * 256 + (b.leaf_idx.size + 1) * 48 + 64 * gi.size + 1024 for b, gi in zip(tl.bvhs, tl.group_insts))
-    for streamed, budget in ((False, 0), (True, 0), (True, 2 * slot)):
+    # (in_place 0: every flushed queue is loaded; None = the default: sparse queues are traced where their image lies, in host memory)
+    for streamed, budget, in_place in ((False, 0, None), (True, 0, 0), (True, 2 * slot, 0), (True, 2 * slot, None)):
         ctx = pa.accel.Context(0)
         try:
             tl.upload(ctx, streamed=streamed)
             if streamed:
                 ctx.set_leaf_cache(budget)
+                if in_place is not None:
+                    ctx.set_leaf_in_place(in_place)
             for kind in (pa.capi.CLOSEST, pa.capi.ANY):
                 got, cnt = ctx.trace(rays, kind=kind)
                 exp = want[kind]
@@ -87,7 +90,7 @@ def test_two_level_instanced_landscape_resident_and_streamed(svdag):
                     assert bad.size == 0, f"streamed {streamed} budget {budget} kind {kind} {k}: {bad.size} rays differ, first {bad[:8]}"
                 for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
                     assert cnt[k] == exp["counters"][k], k
-                if streamed and budget:
+                if streamed and budget and in_place == 0:
                     assert cnt["leaf_loads"] > 2
         finally:
             ctx.close()

@@ -32,10 +32,11 @@ def _rays(mesh):
     return np.ascontiguousarray(np.concatenate([prim, rnd], axis=1))
 
 
-@pytest.mark.parametrize("hold", [0, 256, 4096], ids=["no_waiting", "hold256", "hold4096"])
+@pytest.mark.parametrize("hold,in_place", [(0, 0), (256, 0), (4096, 0), (256, 4096), (1, 1)],
+                         ids=["no_waiting", "hold256", "hold4096", "hold256_sparse_queues_in_host_memory", "everything_in_host_memory"])
 @pytest.mark.parametrize("copy_mode", [0, 1], ids=["gather_kernel", "memcpy_per_image"])
 @pytest.mark.parametrize("svdag", [0, 32])
-def test_streamed_leaves_match_resident(svdag, copy_mode, hold):
+def test_streamed_leaves_match_resident(svdag, copy_mode, hold, in_place):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
@@ -48,6 +49,9 @@ def test_streamed_leaves_match_resident(svdag, copy_mode, hold):
     tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=True)
     ctx.set_leaf_copy(copy_mode)
     ctx.set_leaf_hold(hold)  # rays wait at a point until it holds a ray per `hold` bytes of image (more rounds, fewer loads, same results)
+    # flushed queues with fewer rays than one per `in_place` bytes of image are traced where the image lies, in pinned host memory
+    # (last case: every queue waits and every flush is sparse -- no image is ever loaded unless it is in the cache already)
+    ctx.set_leaf_in_place(in_place)
     slot = max(((b.n_nodes * 256 + 255) // 256) * 256 + (((b.leaf_idx.size + 1) * 48 + 255) // 256) * 256 for b in tl.bvhs)  # (records end in one zero record of padding)
     total = sum(((b.n_nodes * 256 + 255) // 256) * 256 + (((b.leaf_idx.size + 1) * 48 + 255) // 256) * 256 for b in tl.bvhs)
     for budget, label in ((0, "all fit"), (3 * slot + 17, "3 slots"), (slot, "1 slot"), (total // 2, "half"), (total - 256, "all but one")):
@@ -62,7 +66,9 @@ def test_streamed_leaves_match_resident(svdag, copy_mode, hold):
                 assert cnt[k] == ecnt[k], f"{label}: {k}"
             assert cnt["rounds"] == ecnt["rounds"] if hold == 0 else cnt["rounds"] >= ecnt["rounds"], f"{label}: rounds"
             # (a trace that finds everything it needs in the cache loads nothing: possible once the cache holds half of the images)
-            assert cnt["leaf_loads"] > 0 or budget == 0 or budget >= total // 2
+            assert cnt["leaf_loads"] > 0 or budget == 0 or budget >= total // 2 or in_place
+            if in_place == 1:
+                    assert cnt["leaf_loads"] <= 2, f"{label}: only an image smaller in bytes than its queue in rays qualifies for a load"
             if budget and budget < 4 * slot and hold == 0:
                 assert cnt["leaf_loads"] > budget // slot, f"{label}: more BVHs were needed than fit, so space must have been recycled (loads {cnt['leaf_loads']})"
             assert cnt["streamed_bytes"] >= cnt["leaf_loads"] * 256 or cnt["leaf_loads"] == 0
@@ -169,17 +175,19 @@ def test_streamed_city_random_cache_settings():
     try:
         tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=True)
         loads = []
-        for trial in range(8):
+        for trial in range(12):
             budget = int(rng.uniform(max(images), sum(images)))
             hold = int(rng.choice([0, 16, 256, 2048, 1 << 20]))
+            in_place = int(rng.choice([0, 1, 512, 4096]))
             ctx.set_leaf_cache(budget)
             ctx.set_leaf_hold(hold)
+            ctx.set_leaf_in_place(in_place)
             ctx.set_leaf_copy(trial & 1)
             for kind in (pa.capi.CLOSEST, pa.capi.ANY):
                 got, cnt = ctx.trace(rays, kind=kind)
                 exp, ecnt = want[kind]
                 for k in (("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")):
-                    assert np.array_equal(_bits(got[k]), _bits(exp[k])), f"budget {budget} hold {hold}: {k}"
+                    assert np.array_equal(_bits(got[k]), _bits(exp[k])), f"budget {budget} hold {hold} in place {in_place}: {k}"
                 for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
                     assert cnt[k] == ecnt[k], f"budget {budget} hold {hold}: {k}"
                 assert cnt["rounds"] >= ecnt["rounds"]

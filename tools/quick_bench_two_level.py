@@ -27,6 +27,8 @@ ctx = pa.accel.Context(0)
 tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=cache_mb >= 0)
 if cache_mb >= 0:
     ctx.set_leaf_cache(int(cache_mb * (1 << 20)))
+    if "LEAF_HOLD" in os.environ:
+        ctx.set_leaf_hold(int(os.environ["LEAF_HOLD"]))
     ctx.set_leaf_copy(int(os.environ.get("LEAF_COPY", "0")))  # 0: one gather kernel per launch group, 1: one hipMemcpyAsync per image
     print("streamed leaves: %.1f MB of BVH images in host memory, cache %s" % (
         sum(b.n_nodes * 256 + b.leaf_idx.size * 48 for b in tl.bvhs) / 1e6, "holds all" if cache_mb == 0 else "%.0f MB" % cache_mb), flush=True)
