@@ -174,6 +174,9 @@ int traceLeafGroups(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint3
 // launch over the stretch of the list the points span, through a view of the BVH table in which only they are visible
 int traceLeavesInPlace(pgpu_ctx* c, Bvh8TraceArgs ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& points, const uint32_t* leafStart,
     const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream);
+int prepareLeafTableView(pgpu_ctx* c, hipStream_t stream); // (once per trace, before traceLeavesInPlace / traceLeafListStreamed)
+int traceLeafListStreamed(pgpu_ctx* c, const Bvh8TraceArgs& ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& points, const uint32_t* leafStart,
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream);
 // route_abi.hip. instRows: closest-hit result rows have five values (the instance of the hit last), see launchPackResults
 // (cursor / spill: for a launch that runs next to another bottom-level launch of the same context; default = the context's)
 int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, size_t k, float* results, hipStream_t stream, bool instRows = false,

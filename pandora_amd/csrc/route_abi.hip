@@ -129,7 +129,7 @@ int traceLeafRecords(pgpu_ctx* c, int kind, int tri_mode, const float* records, 
             if (hCount[l] != 0u)
                 order.push_back(uint32_t(l));
         }
-        rc = traceLeafGroups(c, ba, kind, tri_mode, deepest, order, hStart.data(), hCount.data(), cursor, spill, stream);
+        rc = traceLeafListStreamed(c, ba, kind, tri_mode, deepest, order, hStart.data(), hCount.data(), cursor, spill, stream);
         if (rc != PGPU_OK)
             return rc;
     } else {

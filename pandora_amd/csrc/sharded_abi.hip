@@ -548,7 +548,8 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     if (closest)
         resultBytes = instRows ? 20 : 16;
     if (streamed)
-        soft(prepareLeafCache(c)); // (the arena, the copy stream, the pinned per-point arrays)
+        if (soft(prepareLeafCache(c))) // (the arena, the copy stream, the pinned per-point arrays)
+            soft(prepareLeafTableView(c, stream)); // (launches that trace sparse queues in host memory see the BVH table through a view)
     {
         // the in-place trace of the rays parked at this rank's own points: at most n work items, overflow buffer of its own
         Bvh8TraceArgs probe = ba;
@@ -663,7 +664,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
                     std::reverse(visitOrder.begin(), visitOrder.end());
                 ba.work_bvh = dWorkBvh;
                 ba.work_tag = dWorkLeaf;
-                soft(traceLeafGroups(c, ba, kind, tri_mode, deepest, visitOrder, hLeafStart.data(), hCount, cursorLocal, &c->spillB, stream));
+                soft(traceLeafListStreamed(c, ba, kind, tri_mode, deepest, visitOrder, hLeafStart.data(), hCount, cursorLocal, &c->spillB, stream));
             } else if (softHip(hipMemsetAsync(cursorLocal, 0, 256, localStream), "hipMemsetAsync") && soft(planBvh8Launch(c, deepest, parked, ba, &blocks, &c->spillB)))
                 softHip(launchBvh8Trace(ba, kind, tri_mode, c->stats, blocks, localStream), "bottom-level trace");
             if (forked)

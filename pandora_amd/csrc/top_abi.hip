@@ -245,6 +245,34 @@ namespace pandora_hip {
 
 int prepareLeafCache(pgpu_ctx* c) { return ensureLeafCache(c); }
 
+int prepareLeafTableView(pgpu_ctx* c, hipStream_t stream)
+{
+    const int rc = prepareTableView(c);
+    return rc == PGPU_OK ? fillTableView(c, stream) : rc;
+}
+
+// The loops that do not let rays wait (pgpu_trace_sharded: the rays parked at this rank's own points, and the records other
+// ranks sent): a point whose queue is worth its image -- a ray per leafHoldBytesPerRay bytes -- is loaded (launch groups of what
+// fits the cache together), the rays of the others traverse their image where it lies, in host memory.
+int traceLeafListStreamed(pgpu_ctx* c, const Bvh8TraceArgs& ba, int kind, int tri_mode, uint32_t deepest, const std::vector<uint32_t>& points, const uint32_t* leafStart,
+    const uint32_t* leafCount, uint32_t* cursor, DeviceBuffer* spill, hipStream_t stream)
+{
+    std::vector<uint32_t> load, inPlace;
+    for (uint32_t l : points) {
+        const uint32_t id = c->topLeavesHost[l].bvh;
+        const StagedBvh* im = (id < c->staged.size() && c->staged[id].host) ? &c->staged[id] : nullptr;
+        const bool sparse = im && !im->resident && c->leafInPlaceBytesPerRay != 0u && c->leafHoldBytesPerRay != 0u && c->tableView.ptr
+            && uint64_t(leafCount[l]) * c->leafHoldBytesPerRay < im->imageBytes() && uint64_t(leafCount[l]) * c->leafInPlaceBytesPerRay < im->imageBytes();
+        (sparse ? inPlace : load).push_back(l);
+    }
+    int rc = load.empty() ? PGPU_OK : traceLeafGroups(c, ba, kind, tri_mode, deepest, load, leafStart, leafCount, cursor, spill, stream);
+    if (rc == PGPU_OK && !inPlace.empty()) {
+        std::sort(inPlace.begin(), inPlace.end());
+        rc = traceLeavesInPlace(c, ba, kind, tri_mode, deepest, inPlace, leafStart, leafCount, cursor, spill, stream);
+    }
+    return rc;
+}
+
 // Bottom-level traversal of a work list that is sorted by batching point, through BVHs that may be staged in host memory: the
 // points of `visitOrder` (ascending or descending slots) whose images fit the HBM cache together form one launch over the
 // contiguous stretch of the list they span; the copies of a group run on the copy stream, behind the last launch that read the

@@ -132,6 +132,7 @@ def instanced_landscape(out_dir, kind, rank, world, dev, streamed=False):
         order = np.asarray(tl.top.leaf_order, np.int64)
         image = [tl.bvhs[g].n_nodes * 256 + (tl.bvhs[g].leaf_idx.size + 1) * 48 + 64 * tl.group_insts[g].size + 1024 for s, g in enumerate(order) if owner[s] == rank]
         ctx.set_leaf_cache(max(2 * max(image), sum(image) // 5))
+        ctx.set_leaf_in_place(0)  # first with every queue's image loaded; the second trace below with sparse queues traced in host memory
     rays = np.load(os.path.join(out_dir, "rays.npy"))[:, rank::world]
     d_rays = torch.from_numpy(np.ascontiguousarray(rays)).to(dev)
     sharded.comm_init(ctx, dev, host_staged=True)
@@ -139,9 +140,11 @@ def instanced_landscape(out_dir, kind, rank, world, dev, streamed=False):
     st, cnt = ctx.trace_sharded(d_rays, kind=kind)
     if streamed:
         assert cnt["leaf_loads"] > len(image) and cnt["streamed_bytes"] > sum(image), "the cache holds a fifth of this rank's images: they must be loaded more than once"
-        st2, cnt2 = ctx.trace_sharded(d_rays, kind=kind)  # again, from a warm cache: same results
+        ctx.set_leaf_in_place(128)  # (the default)
+        st2, cnt2 = ctx.trace_sharded(d_rays, kind=kind)  # again, from a warm cache and with sparse queues traced where their image lies: same results
         for k in st:
             assert torch.equal(st[k], st2[k]), k
+        assert cnt2["leaf_loads"] < cnt["leaf_loads"]
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), routed=cnt["records_routed"], rounds=cnt["rounds"], leaf_visits=cnt["leaf_visits"],
              svdag_tests=cnt["svdag_tests"], svdag_culled=cnt["svdag_culled"], **{k: v.cpu().numpy() for k, v in st.items()})
     ctx.close()
