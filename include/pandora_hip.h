@@ -500,10 +500,13 @@ int pgpu_set_round_lookahead(pgpu_ctx*, int on);
  * (No counterpart in the reference, whose CPU tasks already run side by side, task_graph.h:259-292.) */
 int pgpu_set_batch_parts(pgpu_ctx*, int parts);
 /* The top-level kernel of pgpu_trace: 1 = waves in lockstep (64 rays start an episode together and the wave waits for the
- * slowest), 2 = lanes take the next ray as soon as theirs has parked or left, and a wave runs BVH4 steps and SVDAG cast trips
- * as separate phases, 3 = lockstep waves for a trace's first episode (every ray from the root) and variant 2 for the resumed rays
- * of the later rounds, 0 = automatic. refill_min = idle lanes of a wave before it fetches new rays, cast_trips = cast trips
- * per cast phase (0 = defaults; variants 2 and 3). Results do not depend on any of them. */
+ * slowest), a ray's SVDAG cast running inside the step that reached the DAG; 4 = the same waves with the casts gathered: a wave
+ * walks until every ray has parked, left or stands in front of a DAG, then runs all those casts together, then the rays whose
+ * cast missed walk on (a few cast phases per episode instead of one per step); 2 = lanes take the next ray as soon as theirs has
+ * parked or left, and a wave runs BVH4 steps and SVDAG cast trips as separate phases; 3 = variant 1 for a trace's first episode
+ * (every ray from the root) and variant 2 for the resumed rays of the later rounds; 0 = automatic (4). refill_min = idle lanes of
+ * a wave before it fetches new rays, cast_trips = cast trips per cast phase (0 = defaults; variants 2 and 3). Results do not
+ * depend on any of them. */
 int pgpu_set_top_variant(pgpu_ctx*, int variant, int refill_min, int cast_trips);
 
 #ifdef __cplusplus

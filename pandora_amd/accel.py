@@ -617,7 +617,8 @@ class Context:
         _check(self._L.pgpu_film_allreduce(self._h, capi.ptr(film), int(film.numel() // 3), stream), self._h)
 
     def set_top_variant(self, variant: int = 0, refill_min: int = 0, cast_trips: int = 0):
-        """Top-level kernel of trace(): 1 lockstep waves, 2 lanes refilled as their rays finish, 0 automatic. Same results."""
+        """Top-level kernel of trace(): 1 lockstep waves with casts inside the step, 4 the same with a wave's casts gathered into phases,
+        2 lanes refilled as their rays finish, 3 = 1 for the first episode then 2, 0 automatic (4). Same results."""
         _check(self._L.pgpu_set_top_variant(self._h, variant, refill_min, cast_trips), self._h)
 
     def set_round_lookahead(self, on: bool = True):

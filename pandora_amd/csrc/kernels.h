@@ -150,6 +150,7 @@ struct TopTraceArgs {
     // topTraverseLanesKernel (lanes refilled as their rays finish) instead of the lockstep kernel: idle lanes of a wave before
     // it fetches new rays (0 = use the lockstep kernel), cast trips per turn of the cast phase
     uint32_t lanes_refill_min, lanes_cast_trips;
+    uint32_t phased; // the lockstep kernel with its SVDAG casts gathered into phases of the whole wave (top_kernels.hip)
 };
 
 // The SVDAG casts of one pass as a kernel of their own. Requests (positions of the round's list) arrive sorted by batching

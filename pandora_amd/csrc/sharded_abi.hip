@@ -459,6 +459,7 @@ int pgpu_trace_sharded(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* ray
     ta.parked_leaf = dParked;
     ta.leaf_count = dLeafCount;
     ta.step_cap = uint32_t(std::min<uint64_t>(0xFFFFFFF0ull, 8ull * (uint64_t(c->top.n_nodes) + c->top.n_leaves) + 64ull));
+    ta.phased = c->topVariant != 1 ? 1u : 0u; // (the casts of a wave gathered into phases, top_kernels.hip)
     ta.counters = c->topCounters;
 
     Bvh8TraceArgs ba {};

@@ -445,7 +445,7 @@ extern "C" {
 
 int pgpu_set_top_variant(pgpu_ctx* c, int variant, int refill_min, int cast_trips)
 {
-    if (!c || variant < 0 || variant > 3 || refill_min < 0 || refill_min > 64 || cast_trips < 0 || cast_trips > 64)
+    if (!c || variant < 0 || variant > 4 || refill_min < 0 || refill_min > 64 || cast_trips < 0 || cast_trips > 64)
         return PGPU_ERR_INVALID;
     c->topVariant = variant;
     c->topRefillMin = refill_min ? uint32_t(refill_min) : 16u;
@@ -811,6 +811,7 @@ static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
     ta.counters = dCounters;
     ta.lanes_refill_min = c->topVariant == 2 ? c->topRefillMin : 0u; // (variant 3: set per round below)
     ta.lanes_cast_trips = c->topCastTrips;
+    ta.phased = (c->topVariant == 0 || c->topVariant == 4) ? 1u : 0u; // (0 = automatic: the phased form; 1 = casts inside the step)
     // the next episode's list: the binning's (rays of one batching point adjacent: coherent waves) or the parked rays in ray-id order
     // (coalesced reads; a kernel whose lanes are independent has no coherence to lose)
     const bool listById = c->topVariant == 2 || c->topVariant == 3;
@@ -1537,6 +1538,7 @@ int pgpu_top_episode(pgpu_ctx* c, int kind, const pgpu_rays* rays, const uint32_
     ta.counters = c->topCounters;
     ta.step_cap = uint32_t(std::min<uint64_t>(0xFFFFFFF0ull, 8ull * (uint64_t(c->top.n_nodes) + c->top.n_leaves) + 64ull));
     ta.may_park = may_park ? 1u : 0u;
+    ta.phased = c->topVariant != 1 ? 1u : 0u;
     const uint32_t perCU = uint32_t(std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / ((topTraverseLdsBytes(c->top) + 1023u) & ~size_t(1023)))));
     const uint32_t blocks = std::max(1u, std::min(uint32_t(c->numCUs) * perCU, uint32_t((n_active + 255) / 256)));
     HIP_TRY(c, launchTopTraverse(ta, kind, blocks, stream));

@@ -272,7 +272,11 @@ __device__ __forceinline__ void loadDirection(const TopTraceArgs& a, uint32_t ra
     dz = a.dz[ray];
 }
 
-template <bool ANY, bool NODES_IN_LDS, bool DEFER>
+// PHASED: a wave walks until every one of its rays has parked, left, or stands in front of a batching point's DAG, and only then
+// runs the casts -- all of them together -- after which the rays whose cast missed walk on. In the plain form a cast runs inside
+// the step that reached the DAG, so the rest of the wave waits for every cast of every step; phased, a wave runs a few cast
+// phases per episode instead of one per step. The sequence of operations of each ray is the same.
+template <bool ANY, bool NODES_IN_LDS, bool DEFER, bool PHASED = false>
 __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void topTraverseKernel(TopTraceArgs a)
 {
     // dynamic LDS: [dag_levels x 256 saved parents of the SVDAG cast][the top-level nodes, when they fit]
@@ -316,7 +320,13 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
             uint32_t node = a.node[ray];
             uint64_t stack = a.stack[ray];
             uint32_t steps = 0;
+            bool pending = false; // PHASED: the ray stands in front of the DAG of batching point `leafId`
+            for (;;) { // (PHASED: walk phase, cast phase, walk phase, ...; otherwise once through)
+            // (Ending a walk phase early, once only a half / third / quarter / eighth of the rays that began it still walk, so that
+            // the rays that are ready do not wait for the stragglers: measured, within noise of waiting for all of them.)
             for (;;) {
+                if (PHASED && pending)
+                    break;
                 if (++steps > a.step_cap)
                     break; // non-terminating traversal (kernels.h): the ray leaves the top level
                 const float* nf = reinterpret_cast<const float*>(nodeBase + size_t(node) * kTopNodeBytes);
@@ -356,6 +366,11 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                                 leafId = leaf;
                                 break;
                             }
+                            if (PHASED && lf.has_dag != 0u) {
+                                pending = true; // (the cast runs when the whole wave has got this far; a miss resumes at this node)
+                                leafId = leaf;
+                                continue;
+                            }
                             if (lf.has_dag != 0u) {
                                 ++nTests;
                                 const SvdagDev dag { lf.root, { lf.bmin[0], lf.bmin[1], lf.bmin[2] }, lf.invExtent, lf.levels, 0u, 0u };
@@ -379,6 +394,21 @@ __global__ __launch_bounds__(kTopBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 if (stack == 0xFFFFFFFFFFFFFFFFull)
                     break;
                 node = nu[26];
+            }
+            if (!PHASED || !pending)
+                break;
+            {
+                // the cast phase: every ray of the wave that stands in front of a DAG
+                const LeafDagDev lf = a.top.leafDags[leafId];
+                ++nTests;
+                const SvdagDev dag { lf.root, { lf.bmin[0], lf.bmin[1], lf.bmin[2] }, lf.invExtent, lf.levels, 0u, 0u };
+                pending = false;
+                if (svdagHit(a.top.dagWords, dag, ox, oy, oz, dx, dy, dz, dagStack + threadIdx.x, kTopBlock)) {
+                    parked = a.may_park != 0u;
+                    break;
+                }
+                ++nCulled;
+            }
             }
             if (parked || deferred) {
                 a.node[ray] = node;
@@ -1021,6 +1051,8 @@ hipError_t launchTopTraverse(const TopTraceArgs& a, int kind, uint32_t blocks, h
             hipLaunchKernelGGL((topTraverseLanesKernel<ANYV, LDSV>), grid, block, ldsBytes, stream, a);         \
         else if (defer)                                                                                          \
             hipLaunchKernelGGL((topTraverseKernel<ANYV, LDSV, true>), grid, block, ldsBytes, stream, a);        \
+        else if (a.phased != 0u)                                                                                 \
+            hipLaunchKernelGGL((topTraverseKernel<ANYV, LDSV, false, true>), grid, block, ldsBytes, stream, a); \
         else                                                                                                     \
             hipLaunchKernelGGL((topTraverseKernel<ANYV, LDSV, false>), grid, block, ldsBytes, stream, a);       \
     } while (0)

@@ -85,7 +85,7 @@ def test_deferred_svdag_casts_match_oracle(two_level, passes):
         ctx.set_svdag_defer(0)
 
 
-@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("variant", [2, 3, 4])
 @pytest.mark.parametrize("refill_min,cast_trips", [(0, 0), (1, 1), (64, 8), (7, 3)])
 def test_top_level_lanes_kernel_matches_oracle(two_level, refill_min, cast_trips, variant):
     """pgpu_set_top_variant(2): the top-level kernel whose lanes take the next ray as soon as theirs has parked or left, with
@@ -154,7 +154,7 @@ def test_a_batch_cut_into_parts_matches_oracle(two_level, parts):
 
 
 @pytest.mark.parametrize("n", [1, 63, 256, 257, 1025])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_tiny_batches_through_the_round_loop(two_level, n, variant):
     """Batches smaller than a block, a wave, a compaction slice: the rounds queued ahead size their launches from the previous
     counts and must neither drop nor repeat a ray."""

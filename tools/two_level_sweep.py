@@ -77,7 +77,7 @@ settings = [dict(), dict(), dict(pol=1)]
 if os.environ.get("SWEEP", "0") == "1":
     settings = [dict()] + [dict(chunk=c) for c in (32, 64, 256)] + [dict(refill=r) for r in (3, 4, 8, 12)] + [dict(leaf=l) for l in (4, 6, 12, 16)] + [dict(bpc=b) for b in (3, 5)] + [dict()]
 if os.environ.get("SWEEP", "0") == "top":  # the top-level kernel's variants (pgpu_set_top_variant)
-    settings = [dict(), dict(top=2), dict(top=3)] + [dict(top=3, trefill=r, trips=t) for r in (8, 24, 32) for t in (2, 8)] + [dict(top=3, pol=1), dict(pol=1), dict()]
+    settings = [dict(), dict(top=4), dict(top=4, parts=1), dict(parts=1), dict(top=4, pol=1), dict(top=2), dict(top=3)] + [dict(top=3, trefill=r, trips=t) for r in (8, 24, 32) for t in (2, 8)] + [dict(top=3, pol=1), dict(pol=1), dict()]
 if os.environ.get("SWEEP", "0") == "parts":  # a batch as parts side by side (pgpu_set_batch_parts)
     settings = [dict(parts=1), dict(parts=2), dict(parts=3), dict(parts=4), dict(parts=2, top=3), dict(parts=3, top=3), dict(parts=2, pol=1), dict(parts=1)]
 for s in settings:
