@@ -255,7 +255,7 @@ struct LeafTableFix {
 static_assert(sizeof(LeafCopySeg) == 64 && sizeof(LeafTableFix) <= 64, "one 64-byte record each");
 hipError_t launchLeafGather(const LeafCopySeg* segs, uint32_t nSegs, uint32_t nChunks, uint32_t blocks, hipStream_t stream);
 hipError_t launchAddCounts(uint32_t* count, const uint32_t* add, uint32_t n, hipStream_t stream);
-hipError_t launchSplitByLeaf(const uint32_t* workRay, const uint32_t* leafStart, const uint32_t* leafCount, const uint32_t* dst, uint32_t nLeaves,
+hipError_t launchSplitByLeaf(const uint32_t* workRay, const uint32_t* leafStart, const uint32_t* leafCount, const uint32_t* dst, uint32_t nLeaves, uint32_t nItems,
     uint32_t* nextActive, uint32_t* heldRay, uint32_t* heldLeaf, uint32_t blocks, hipStream_t stream);
 // (arrivalGroup, optional: per BVH id the launch group it arrived with, see launchLeafTableView)
 hipError_t launchLeafTableFix(const unsigned char* fixes64, uint32_t nFixes, Bvh8Dev* table, hipStream_t stream, uint32_t* arrivalGroup = nullptr);

@@ -86,22 +86,32 @@ __global__ void addCountsKernel(uint32_t* __restrict__ count, const uint32_t* __
 
 // ... and after the round the binned list (sorted by batching point) is split: the rays of the points that were traced form
 // the next round's list, the rays of the others the next held list. dst[l] = where point l's rays go; bit 31 = held.
+// (One thread per list position, the position's point by binary search over the starts: a block per point leaves the few points
+// that hold most of a round's rays to one block each -- 0.2 ms per launch on the benchmark landscape.)
 __global__ __launch_bounds__(256) void splitByLeafKernel(const uint32_t* __restrict__ workRay, const uint32_t* __restrict__ leafStart,
-    const uint32_t* __restrict__ leafCount, const uint32_t* __restrict__ dst, uint32_t nLeaves, uint32_t* __restrict__ nextActive,
+    const uint32_t* __restrict__ leafCount, const uint32_t* __restrict__ dst, uint32_t nLeaves, uint32_t nItems, uint32_t* __restrict__ nextActive,
     uint32_t* __restrict__ heldRay, uint32_t* __restrict__ heldLeaf)
 {
-    for (uint32_t l = blockIdx.x; l < nLeaves; l += gridDim.x) {
-        const uint32_t n = leafCount[l], from = leafStart[l], d = dst[l];
-        const bool held = (d & 0x80000000u) != 0u;
-        const uint32_t to = d & 0x7FFFFFFFu;
-        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
-            const uint32_t ray = workRay[from + i];
-            if (held) {
-                heldRay[to + i] = ray;
-                heldLeaf[to + i] = l;
-            } else {
-                nextActive[to + i] = ray;
-            }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nItems; i += gridDim.x * 256u) {
+        // the last point whose range starts at or before i (empty points share their start with the next one)
+        uint32_t lo = 0, hi = nLeaves;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (leafStart[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t l = lo;
+        const uint32_t at = i - leafStart[l];
+        if (at >= leafCount[l])
+            continue; // (cannot happen for a list that the starts and counts describe)
+        const uint32_t d = dst[l], to = (d & 0x7FFFFFFFu) + at, ray = workRay[i];
+        if (d & 0x80000000u) {
+            heldRay[to] = ray;
+            heldLeaf[to] = l;
+        } else {
+            nextActive[to] = ray;
         }
     }
 }
@@ -114,10 +124,13 @@ hipError_t launchAddCounts(uint32_t* count, const uint32_t* add, uint32_t n, hip
     return hipGetLastError();
 }
 
-hipError_t launchSplitByLeaf(const uint32_t* workRay, const uint32_t* leafStart, const uint32_t* leafCount, const uint32_t* dst, uint32_t nLeaves,
+hipError_t launchSplitByLeaf(const uint32_t* workRay, const uint32_t* leafStart, const uint32_t* leafCount, const uint32_t* dst, uint32_t nLeaves, uint32_t nItems,
     uint32_t* nextActive, uint32_t* heldRay, uint32_t* heldLeaf, uint32_t blocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(splitByLeafKernel, dim3(blocks < nLeaves ? blocks : nLeaves), dim3(256), 0, stream, workRay, leafStart, leafCount, dst, nLeaves,
+    if (nItems == 0u || nLeaves == 0u)
+        return hipSuccess;
+    const uint32_t need = (nItems + 255u) / 256u;
+    hipLaunchKernelGGL(splitByLeafKernel, dim3(blocks < need ? blocks : need), dim3(256), 0, stream, workRay, leafStart, leafCount, dst, nLeaves, nItems,
         nextActive, heldRay, heldLeaf);
     return hipGetLastError();
 }

@@ -1255,7 +1255,7 @@ static int traceBatch(pgpu_ctx* c, int kind, int tri_mode, const pgpu_rays* rays
             if (nextHeld) {
                 // (pinned sources, rewritten only after the next round's synchronisation)
                 HIP_TRY(c, hipMemcpyAsync(dHeldCount, c->leafHostBuf + nl, 2 * nl * 4, hipMemcpyHostToDevice, stream));
-                HIP_TRY(c, launchSplitByLeaf(workRayOut, dLeafStart, dLeafCount, dSplitDst, uint32_t(nl), dNextActive, dHeldRay[heldBuf ^ 1u],
+                HIP_TRY(c, launchSplitByLeaf(workRayOut, dLeafStart, dLeafCount, dSplitDst, uint32_t(nl), parked, dNextActive, dHeldRay[heldBuf ^ 1u],
                                dHeldLeaf[heldBuf ^ 1u], uint32_t(c->numCUs) * 4u, stream));
                 heldBuf ^= 1u;
             }
