@@ -175,7 +175,7 @@ def test_streamed_city_random_cache_settings():
     try:
         tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx), streamed=True)
         loads = []
-        for trial in range(12):
+        for trial in range(16):
             budget = int(rng.uniform(max(images), sum(images)))
             hold = int(rng.choice([0, 16, 256, 2048, 1 << 20]))
             in_place = int(rng.choice([0, 1, 512, 4096]))
@@ -183,11 +183,13 @@ def test_streamed_city_random_cache_settings():
             ctx.set_leaf_hold(hold)
             ctx.set_leaf_in_place(in_place)
             ctx.set_leaf_copy(trial & 1)
+            layout = int(rng.choice([0, 2, 4]))  # (4: the quad kernel, whose nodes go to LDS by direct loads -- from host memory too)
+            ctx.set_ray_layout(layout)
             for kind in (pa.capi.CLOSEST, pa.capi.ANY):
                 got, cnt = ctx.trace(rays, kind=kind)
                 exp, ecnt = want[kind]
                 for k in (("hit", "visits") if kind == pa.capi.ANY else ("t", "obj", "leaf", "u", "v", "visits")):
-                    assert np.array_equal(_bits(got[k]), _bits(exp[k])), f"budget {budget} hold {hold} in place {in_place}: {k}"
+                    assert np.array_equal(_bits(got[k]), _bits(exp[k])), f"budget {budget} hold {hold} in place {in_place} layout {layout}: {k}"
                 for k in ("svdag_tests", "svdag_culled", "leaf_visits"):
                     assert cnt[k] == ecnt[k], f"budget {budget} hold {hold}: {k}"
                 assert cnt["rounds"] >= ecnt["rounds"]
