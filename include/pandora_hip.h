@@ -61,6 +61,18 @@ const uint32_t* pgpu_host_bvh8_leaf_indices(const pgpu_host_bvh8*, size_t* n_ind
 uint32_t pgpu_host_bvh8_root(const pgpu_host_bvh8*);
 int pgpu_host_bvh8_depth(const pgpu_host_bvh8*); /* nested inner nodes on the longest path */
 void pgpu_host_bvh8_free(pgpu_host_bvh8*);
+/* The BVH8s of many triangle groups (batching points) at once, built on the GPU of `ctx` (pandora_amd/csrc/bvh_build.hip; the
+ * reference builds one tree per batching point with Embree on the CPU, wive_bvh8_build8_impl.h:87-104, offline_bvh_cache.cpp:273-309):
+ * Morton order per group, one binary radix tree over all groups, boxes bottom-up, collapse into 8-wide nodes, the reference's
+ * 256-byte nodes and octant words written by the device. Group g = triangles group_prims[group_offsets[g] .. group_offsets[g+1])
+ * of the mesh (host arrays; offsets start at 0 and increase); out[g] receives the same kind of object pgpu_build_bvh8 returns
+ * (leaf object j of a group = its j-th triangle) and is freed with pgpu_host_bvh8_free. Trees are of LBVH quality (about a fifth
+ * more node visits per ray than pgpu_build_bvh8's) and built some hundred times faster. A group whose device tree would nest
+ * deeper than 12 inner nodes is built by pgpu_build_bvh8 instead; *n_host_built (may be NULL) says how many were.
+ * pgpu_last_kernel_ms = device time of the build. max_leaf in 1..4, at most 2^20 groups and 2^31 - 2 triangles in all. */
+int pgpu_build_bvh8_device(pgpu_ctx*, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, pgpu_host_bvh8** out,
+    uint32_t* n_host_built);
 /* BVH8 over arbitrary leaf objects given by their bounds (n_objects x {min xyz, max xyz}); leaf object j = box j. An object
  * with alone[j] != 0 gets a leaf of its own (instances; alone may be NULL). What LRUBVHSceneCache::createBVH builds over
  * the mix of instanced sub-scenes and triangles of a sub-scene (offline_bvh_cache.cpp:273-309). */

@@ -74,6 +74,38 @@ def build_bvh8(pos: np.ndarray, idx: np.ndarray, prim_ids: np.ndarray | None = N
         L.pgpu_host_bvh8_free(h)
 
 
+def build_bvh8_device(ctx: "Context", pos: np.ndarray, idx: np.ndarray, groups: "list[np.ndarray] | None" = None, max_leaf: int = 4):
+    """The BVH8s of the triangle groups `groups` (None: one group, the whole mesh) built on the GPU of `ctx`
+    (pgpu_build_bvh8_device: LBVH collapsed into 8-wide nodes). -> (list of HostBvh8, groups the host builder had to take because
+    the device tree nested too deep). ctx.last_kernel_ms() = device time of the build."""
+    L = capi.lib()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    if groups is None:
+        groups = [np.arange(idx.shape[0], dtype=np.uint32)]
+    groups = [np.ascontiguousarray(g, np.uint32) for g in groups]
+    offsets = np.zeros(len(groups) + 1, np.uint64)
+    offsets[1:] = np.cumsum([g.size for g in groups])
+    prims = np.ascontiguousarray(np.concatenate(groups), np.uint32)
+    handles = (C.c_void_p * len(groups))()
+    host_built = C.c_uint32()
+    _check(L.pgpu_build_bvh8_device(ctx._h, pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prims.ctypes.data, offsets.ctypes.data, len(groups),
+                                    max_leaf, handles, C.byref(host_built)), ctx._h, what="pgpu_build_bvh8_device failed")
+    out = []
+    try:
+        for g, h in zip(groups, handles):
+            n = C.c_size_t()
+            p = L.pgpu_host_bvh8_nodes(h, C.byref(n))
+            nodes = capi.view(p, n.value * 64, np.float32).reshape(-1, 64).copy() if n.value else np.zeros((0, 64), np.float32)
+            p = L.pgpu_host_bvh8_leaf_indices(h, C.byref(n))
+            out.append(HostBvh8(nodes, capi.view(p, n.value, np.uint32).copy(), int(L.pgpu_host_bvh8_root(h)), int(L.pgpu_host_bvh8_depth(h)), g))
+    finally:
+        for h in handles:
+            if h:
+                L.pgpu_host_bvh8_free(h)
+    return out, int(host_built.value)
+
+
 def make_camera(eye, look_at, up, fov_x_deg: float, aspect: float, lens_radius: float = 0.0, focal_distance: float = 1.0) -> "capi.Camera":
     """PerspectiveCamera::updatePosition (graphics_core/perspective_camera.cpp:50-65) in binary32 for a camera whose transform has
     the columns (right, up, forward, eye). The result is what pgpu_camera_rays takes."""
@@ -785,7 +817,7 @@ class TwoLevelScene:
 
 
 def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4, build_group=None,
-                    svdag_device_ctx: "Context | None" = None) -> TwoLevelScene:
+                    svdag_device_ctx: "Context | None" = None, bvh_device_ctx: "Context | None" = None) -> TwoLevelScene:
     """build_group: optional callable (group sizes: int array[, top: HostBvh4]) -> bool array; only those batching points get a
     bottom-level BVH8 here (the others stay None: they live on another rank). A callable that takes two arguments also gets the
     top level, which is built first (from the groups' bounds) so that ownership can follow its leaf order. The cut, the top
@@ -812,7 +844,13 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
         two = len(inspect.signature(build_group).parameters) >= 2
         want = np.asarray(build_group(counts, top) if two else build_group(counts), bool)
     build = lambda gi: build_bvh8(pos, idx, groups[gi], max_leaf) if want[gi] else None
-    if workers > 1:
+    if bvh_device_ctx is not None:  # every wanted batching point's BVH8 in one pass over the GPU (pgpu_build_bvh8_device)
+        sel = [gi for gi in range(ng) if want[gi]]
+        built, _ = build_bvh8_device(bvh_device_ctx, pos, idx, [groups[gi] for gi in sel], max_leaf) if sel else ([], 0)
+        bvhs = [None] * ng
+        for gi, b in zip(sel, built):
+            bvhs[gi] = b
+    elif workers > 1:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(workers) as pool:
             bvhs = list(pool.map(build, range(ng)))

@@ -155,6 +155,8 @@ SYMBOLS = {
     "pgpu_film_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgpu_set_keep_shading": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_build_svdags_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "pgpu_build_bvh8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_uint32)]),
     "pgpu_set_round_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_set_batch_parts": (C.c_int, [C.c_void_p, C.c_int]),
     "pgpu_set_top_variant": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),

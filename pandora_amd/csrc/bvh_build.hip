@@ -1,0 +1,702 @@
+// Bottom-level BVH8 construction on the GPU ("GPU LBVH build"): pgpu_build_bvh8_device.
+//
+// The reference builds its 8-wide trees with Embree on the CPU (wive_bvh8_build8_impl.h:87-104, one rtcBuildBVH per batching
+// point); the host builder of this repository (pandora_amd/host/bvh_builder.cpp) replaces that with a binary SAH tree collapsed
+// by dynamic programming -- the best trees, 2 us per triangle and thread. This file builds the trees of ALL batching points of a
+// scene in one pass over the GPU, for scenes whose construction time matters more than the last 15 % of traversal speed:
+//   1. one thread per triangle: bounds, centroid; per-group centroid bounds (ordered-integer atomics, one per wave when a wave
+//      lies in one group);
+//   2. 64-bit keys  group | Morton code of the centroid inside the group's bounds (as many bits per axis as the group id leaves,
+//      at most 21), one radix sort over all groups (hipCUB): the groups' triangles stay contiguous, in group order;
+//   3. one binary radix tree over the whole sorted array (Karras 2012: every internal node finds its range and split with two
+//      binary searches over common prefix lengths; equal keys fall back to the index) -- the group id is the top of the key, so
+//      every group's triangles are exactly one subtree; its root is the node whose range is the group's;
+//   4. boxes bottom-up (the second thread to arrive at a node computes it);
+//   5. collapse into 8-wide nodes, level by level from all group roots at once: a node adopts the children of the child with
+//      the largest surface until it has eight (subtrees of at most max_leaf triangles are leaves on sight, as in the host's
+//      greedy construction); children too large for what is left of the depth budget are opened first, largest first. Node indices are handed
+//      out per group, so every handle is local to its group's node array from the start;
+//   6. emit: the reference's 256-byte nodes (wive_bvh8.h:76-86) with the octant permutation words of
+//      wive_bvh8_build8_impl.h:172-203, group after group in one array, and the leaf-index arrays (= the sorted order).
+// A group whose tree would nest deeper than the traversal stack allows (12 inner nodes, wive_bvh8_impl.h:74-75) is rebuilt by the
+// host builder, which balances against that budget; the caller learns how many were. Topology is this builder's own (as the host
+// builder's is: Embree is not here); the output is in the reference's layout and goes through the same upload path.
+#include "context.h"
+#include "trace_ranges.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace pandora_hip;
+
+namespace {
+
+constexpr uint32_t kLeafRef = 0x80000000u; // a binary-tree reference to a single sorted triangle
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kMaxLevels = 12; // nested inner nodes: 7 * 12 + 8 <= 96 stack entries
+
+struct Box6 {
+    float lo[3], hi[3];
+};
+struct WorkItem {
+    uint32_t node, local, group;
+};
+struct NodeRec { // one wide node before it is written: its children in the binary tree and their handles
+    uint32_t ref[8];
+    uint32_t handle[8];
+};
+
+__device__ __forceinline__ uint32_t orderedBits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fromOrderedBits(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// ---- 1. triangle bounds, group of every position, centroid bounds per group
+__global__ void __launch_bounds__(256) primBoundsKernel(const float* __restrict__ pos, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ prims,
+    const unsigned long long* __restrict__ offsets, uint32_t nGroups, uint32_t n, uint32_t* __restrict__ groupOf, Box6* __restrict__ primBox,
+    uint32_t* __restrict__ cbounds)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const bool live = p < n;
+    uint32_t g = 0;
+    uint32_t kmin[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, kmax[3] = { 0u, 0u, 0u };
+    if (live) {
+        uint32_t lo = 0, hi = nGroups; // offsets[lo] <= p < offsets[hi]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (offsets[mid] <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        g = lo;
+        const uint32_t t = prims[p];
+        Box6 b;
+        for (int a = 0; a < 3; ++a) {
+            const float v0 = pos[3u * size_t(idx[3u * size_t(t)]) + a], v1 = pos[3u * size_t(idx[3u * size_t(t) + 1u]) + a],
+                        v2 = pos[3u * size_t(idx[3u * size_t(t) + 2u]) + a];
+            b.lo[a] = fminf(v0, fminf(v1, v2));
+            b.hi[a] = fmaxf(v0, fmaxf(v1, v2));
+            const float c = 0.5f * (b.lo[a] + b.hi[a]);
+            kmin[a] = kmax[a] = orderedBits(c);
+        }
+        primBox[p] = b;
+        groupOf[p] = g;
+    }
+    // a wave that lies in one group (nearly all of them) reduces first and sends six atomics instead of 384
+    const uint32_t g0 = uint32_t(__builtin_amdgcn_readfirstlane(int(g)));
+    const bool uniform = __all(!live || g == g0);
+    if (uniform) {
+        for (int s = 32; s >= 1; s >>= 1)
+            for (int a = 0; a < 3; ++a) {
+                kmin[a] = min(kmin[a], uint32_t(__shfl_xor(int(kmin[a]), s)));
+                kmax[a] = max(kmax[a], uint32_t(__shfl_xor(int(kmax[a]), s)));
+            }
+        if ((threadIdx.x & 63u) == 0u && live)
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&cbounds[6u * g0 + a], kmin[a]);
+                atomicMax(&cbounds[6u * g0 + 3u + a], kmax[a]);
+            }
+    } else if (live) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&cbounds[6u * g + a], kmin[a]);
+            atomicMax(&cbounds[6u * g + 3u + a], kmax[a]);
+        }
+    }
+}
+
+// ---- 2. keys: group | Morton code of the centroid in the group's centroid bounds
+__device__ __forceinline__ unsigned long long spread3(uint32_t v) // bit i of v (i < 21) to bit 3 i
+{
+    unsigned long long x = v & 0x1FFFFFu;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) mortonKernel(const Box6* __restrict__ primBox, const uint32_t* __restrict__ groupOf, const uint32_t* __restrict__ cbounds,
+    uint32_t n, int bitsPerAxis, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint32_t g = groupOf[p];
+    const Box6 b = primBox[p];
+    const float cells = float(1u << bitsPerAxis);
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {
+        const float lo = fromOrderedBits(cbounds[6u * g + a]), hi = fromOrderedBits(cbounds[6u * g + 3u + a]);
+        const float c = 0.5f * (b.lo[a] + b.hi[a]);
+        const float ext = hi - lo;
+        float x = ext > 0.0f ? (c - lo) / ext * cells : 0.0f;
+        x = x == x ? x : 0.0f; // (a NaN or infinite vertex: any cell will do, the tree stays a tree)
+        x = fminf(fmaxf(x, 0.0f), cells - 1.0f);
+        q[a] = uint32_t(x);
+    }
+    const unsigned long long morton = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+    keys[p] = (static_cast<unsigned long long>(g) << (3 * bitsPerAxis)) | morton;
+    vals[p] = p;
+}
+
+// ---- 3. binary radix tree (Karras 2012, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", section 4)
+__device__ __forceinline__ int prefixLen(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t i, long long j)
+{
+    if (j < 0 || j >= static_cast<long long>(n))
+        return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b)
+        return 64 + __clz(int(i ^ uint32_t(j))); // equal keys: the positions themselves are the tie-break
+    return __clzll(static_cast<long long>(a ^ b));
+}
+
+__global__ void __launch_bounds__(256) hierarchyKernel(const unsigned long long* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ groupOf,
+    const unsigned long long* __restrict__ offsets, uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ rangeLo,
+    uint32_t* __restrict__ rangeHi, uint32_t* __restrict__ parentInt, uint32_t* __restrict__ parentLeaf, uint32_t* __restrict__ groupRoot)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i + 1u >= n)
+        return;
+    const long long ii = i;
+    const int d = prefixLen(keys, n, i, ii + 1) - prefixLen(keys, n, i, ii - 1) >= 0 ? 1 : -1;
+    const int dMin = prefixLen(keys, n, i, ii - d);
+    long long lMax = 2;
+    while (prefixLen(keys, n, i, ii + lMax * d) > dMin)
+        lMax <<= 1;
+    long long l = 0;
+    for (long long t = lMax >> 1; t >= 1; t >>= 1)
+        if (prefixLen(keys, n, i, ii + (l + t) * d) > dMin)
+            l += t;
+    const long long j = ii + l * d;
+    const int dNode = prefixLen(keys, n, i, j);
+    long long s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (prefixLen(keys, n, i, ii + (s + t) * d) > dNode)
+            s += t;
+    } while (t > 1);
+    const long long gamma = ii + s * d + (d < 0 ? -1 : 0);
+    const uint32_t lo = uint32_t(ii < j ? ii : j), hi = uint32_t(ii < j ? j : ii);
+    const uint32_t gl = uint32_t(gamma), gr = uint32_t(gamma) + 1u;
+    if (gl < lo || gr > hi)
+        return; // (cannot happen on sorted keys; a node left unlinked fails the build instead of writing out of range)
+    const uint32_t leftRef = lo == gl ? (gl | kLeafRef) : gl, rightRef = hi == gr ? (gr | kLeafRef) : gr;
+    left[i] = leftRef;
+    right[i] = rightRef;
+    rangeLo[i] = lo;
+    rangeHi[i] = hi;
+    if (leftRef & kLeafRef)
+        parentLeaf[gl] = i;
+    else
+        parentInt[gl] = i;
+    if (rightRef & kLeafRef)
+        parentLeaf[gr] = i;
+    else
+        parentInt[gr] = i;
+    const uint32_t g = groupOf[lo];
+    if (offsets[g] == lo && offsets[g + 1u] == static_cast<unsigned long long>(hi) + 1ull)
+        groupRoot[g] = i;
+}
+
+// ---- 4. boxes, bottom-up: the second thread to reach a node computes it and goes on
+__device__ __forceinline__ Box6 loadNodeBoxCoherent(const Box6* p) // written by another CU moments ago: past the L1
+{
+    Box6 b;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+    for (int a = 0; a < 3; ++a) {
+        b.lo[a] = __uint_as_float(__hip_atomic_load(w + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b.hi[a] = __uint_as_float(__hip_atomic_load(w + 3 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return b;
+}
+
+__global__ void __launch_bounds__(256) fitKernel(uint32_t n, const uint32_t* __restrict__ order, const Box6* __restrict__ primBox, const uint32_t* __restrict__ left,
+    const uint32_t* __restrict__ right, const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf, uint32_t* __restrict__ visits,
+    Box6* nodeBox)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n)
+        return;
+    uint32_t cur = parentLeaf[p];
+    for (uint32_t guard = 0; cur != kNone && cur + 1u < n && guard < 192u; ++guard) { // (a path is at most 64 + 32 nodes long)
+        __threadfence();
+        if (atomicAdd(&visits[cur], 1u) == 0u)
+            return;
+        __threadfence();
+        const uint32_t l = left[cur], r = right[cur];
+        const Box6 a = (l & kLeafRef) ? primBox[order[l & ~kLeafRef]] : loadNodeBoxCoherent(nodeBox + l);
+        const Box6 b = (r & kLeafRef) ? primBox[order[r & ~kLeafRef]] : loadNodeBoxCoherent(nodeBox + r);
+        Box6 u;
+        for (int k = 0; k < 3; ++k) {
+            u.lo[k] = fminf(a.lo[k], b.lo[k]);
+            u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+        }
+        nodeBox[cur] = u;
+        cur = parentInt[cur];
+    }
+}
+
+// ---- 5. collapse into 8-wide nodes
+__device__ __forceinline__ uint32_t handleInner(uint32_t i) { return (i & 0x1FFFFFFFu) | (2u << 29); }                    // wive_bvh8_impl.h:333-338
+__device__ __forceinline__ uint32_t handleLeaf(uint32_t i, uint32_t n) { return (i & 0x1FFFFFFFu) | ((4u | (n - 1u)) << 29); } // :340-346
+
+// A level of the collapse in two kernels with a scan between them, so that the numbering of the nodes does not depend on the order
+// in which threads happen to run: the level's queue holds its nodes group after group (the seeds are in group order, and the
+// children of a queue in order are a queue in order), expandKernel opens each node's children and counts those that become nodes,
+// an exclusive scan of the counts gives every node the positions of its children in the next queue, and assignKernel hands out the
+// handles: a group's nodes are numbered in breadth-first order -- child c of the queue's k-th node gets
+// (number of the group's first node of this level) + (the group's nodes of this level) + (its position among the group's children).
+__global__ void __launch_bounds__(256) expandKernel(const WorkItem* __restrict__ in, uint32_t nIn, uint32_t level, uint32_t maxLevels, uint32_t maxLeaf, unsigned long long capacity,
+    const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi,
+    const Box6* __restrict__ nodeBox, const unsigned long long* __restrict__ offsets, NodeRec* __restrict__ recs, uint32_t* __restrict__ innerCount,
+    uint32_t* __restrict__ groupDepth, uint32_t* __restrict__ groupFailed)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k > nIn)
+        return;
+    if (k == nIn) { // (one element more, so that the scan also yields the total)
+        innerCount[k] = 0u;
+        return;
+    }
+    const WorkItem w = in[k];
+    uint32_t kids[8];
+    int n = 2;
+    kids[0] = left[w.node];
+    kids[1] = right[w.node];
+    for (int j = 2; j < 8; ++j)
+        kids[j] = kNone;
+    while (n < 8) {
+        // open the child the depth budget cannot hold, else the one with the largest surface; subtrees of <= maxLeaf triangles are leaves
+        int pick = -1;
+        float best = -1.0f;
+        uint32_t most = 0;
+        bool over = false;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t ref = kids[j];
+            if (ref & kLeafRef)
+                continue;
+            const uint32_t cnt = rangeHi[ref] - rangeLo[ref] + 1u;
+            if (cnt <= maxLeaf)
+                continue;
+            if (cnt > capacity) { // (among those: the one with the most triangles, which balances what is left of the budget)
+                if (!over || cnt > most) {
+                    pick = j;
+                    most = cnt;
+                    over = true;
+                }
+                continue;
+            }
+            if (over)
+                continue;
+            const Box6 b = nodeBox[ref];
+            const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (pick < 0 || area > best || (area == best && cnt > most)) { // (equal surfaces, e.g. coincident triangles: the larger)
+                pick = j;
+                best = area;
+                most = cnt;
+            }
+        }
+        if (pick < 0)
+            break;
+        const uint32_t ref = kids[pick];
+        for (int j = n; j > pick + 1; --j)
+            kids[j] = kids[j - 1];
+        kids[pick] = left[ref];
+        kids[pick + 1] = right[ref];
+        ++n;
+    }
+    const uint32_t base = uint32_t(offsets[w.group]);
+    NodeRec r;
+    uint32_t nInner = 0;
+    for (int j = 0; j < 8; ++j) {
+        r.ref[j] = kids[j];
+        r.handle[j] = 0u; // (a child that becomes a node: assignKernel fills it in)
+        if (j >= n)
+            continue;
+        const uint32_t ref = kids[j];
+        if (ref & kLeafRef) {
+            r.handle[j] = handleLeaf((ref & ~kLeafRef) - base, 1u);
+        } else {
+            const uint32_t cnt = rangeHi[ref] - rangeLo[ref] + 1u;
+            if (cnt <= maxLeaf)
+                r.handle[j] = handleLeaf(rangeLo[ref] - base, cnt);
+            else
+                ++nInner;
+        }
+    }
+    if (nInner != 0u && level + 1u >= maxLevels) {
+        groupFailed[w.group] = 1u; // deeper than the traversal stack allows: the host builder takes this group
+        nInner = 0u;
+    }
+    innerCount[k] = nInner;
+    recs[size_t(base) + w.local] = r;
+    atomicMax(&groupDepth[w.group], level + 1u);
+}
+
+__global__ void __launch_bounds__(256) assignKernel(const WorkItem* __restrict__ in, uint32_t nIn, const uint32_t* __restrict__ innerCount, const uint32_t* __restrict__ slotStart,
+    const unsigned long long* __restrict__ offsets, NodeRec* __restrict__ recs, WorkItem* __restrict__ out, uint32_t* __restrict__ groupNodeCount)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= nIn || innerCount[k] == 0u)
+        return;
+    const WorkItem w = in[k];
+    // the stretch of the queue that holds this group's nodes of the level
+    uint32_t lo = 0, hi = k; // first position whose group is w.group
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (in[mid].group < w.group)
+            lo = mid + 1u;
+        else
+            hi = mid;
+    }
+    const uint32_t first = lo;
+    lo = k + 1u;
+    hi = nIn; // first position behind the group
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (in[mid].group <= w.group)
+            lo = mid + 1u;
+        else
+            hi = mid;
+    }
+    const uint32_t end = lo;
+    uint32_t slot = slotStart[k];
+    uint32_t local = in[first].local + (end - first) + (slot - slotStart[first]);
+    NodeRec* const r = recs + size_t(offsets[w.group]) + w.local;
+    for (int j = 0; j < 8; ++j)
+        if (r->ref[j] != kNone && r->handle[j] == 0u) {
+            r->handle[j] = handleInner(local);
+            out[slot++] = WorkItem { r->ref[j], local++, w.group };
+        }
+    atomicMax(&groupNodeCount[w.group], local);
+}
+
+// ---- 6. emit the reference's nodes and the leaf-index arrays
+__global__ void __launch_bounds__(256) emitKernel(uint32_t n, const uint32_t* __restrict__ groupOf, const unsigned long long* __restrict__ offsets,
+    const uint32_t* __restrict__ groupNodeCount, const uint32_t* __restrict__ groupFailed, const uint32_t* __restrict__ nodeBase, const NodeRec* __restrict__ recs,
+    const uint32_t* __restrict__ order, const Box6* __restrict__ primBox, const Box6* __restrict__ nodeBox, unsigned char* __restrict__ nodesOut,
+    uint32_t* __restrict__ leafIdx)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint32_t g = groupOf[p];
+    const uint32_t local = p - uint32_t(offsets[g]);
+    leafIdx[p] = order[p] - uint32_t(offsets[g]); // leaf object j of a group = its j-th triangle (offline_bvh_cache.cpp:303-304)
+    if (groupFailed[g] != 0u || local >= groupNodeCount[g])
+        return;
+    const NodeRec r = recs[p];
+    float lo[8][3], hi[8][3];
+    uint32_t nKids = 0;
+    for (int j = 0; j < 8; ++j) {
+        Box6 b {};
+        if (r.ref[j] != kNone && r.handle[j] != 0u) {
+            b = (r.ref[j] & kLeafRef) ? primBox[order[r.ref[j] & ~kLeafRef]] : nodeBox[r.ref[j]];
+            nKids = uint32_t(j) + 1u;
+        }
+        for (int a = 0; a < 3; ++a) {
+            lo[j][a] = b.lo[a];
+            hi[j][a] = b.hi[a];
+        }
+    }
+    // wive_bvh8_build8_impl.h:172-203: per ray-direction octant the children back to front (stable, absent children first)
+    uint32_t perm[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int oct = 0; oct < 8; ++oct) {
+        const float sx = (oct & 1) ? 1.0f : -1.0f, sy = (oct & 2) ? 1.0f : -1.0f, sz = (oct & 4) ? 1.0f : -1.0f;
+        float dist[8];
+        uint32_t ord[8];
+        for (uint32_t i = 0; i < 8u; ++i) {
+            const float ex = sx < 0.0f ? lo[i][0] : hi[i][0], ey = sy < 0.0f ? lo[i][1] : hi[i][1], ez = sz < 0.0f ? lo[i][2] : hi[i][2];
+            dist[i] = i < nKids ? (ex * sx + ey * sy) + ez * sz : FLT_MAX;
+            ord[i] = i;
+        }
+        for (int i = 1; i < 8; ++i) { // stable insertion sort, descending
+            const uint32_t key = ord[i];
+            const float dk = dist[key];
+            int j = i - 1;
+            while (j >= 0 && dk > dist[ord[j]]) {
+                ord[j + 1] = ord[j];
+                --j;
+            }
+            ord[j + 1] = key;
+        }
+        for (int i = 0; i < 8; ++i)
+            perm[i] |= ord[i] << (3 * oct);
+    }
+    float* nd = reinterpret_cast<float*>(nodesOut + (size_t(nodeBase[g]) + local) * 256u);
+    for (int j = 0; j < 8; ++j) {
+        nd[j] = lo[j][0];
+        nd[8 + j] = hi[j][0];
+        nd[16 + j] = lo[j][1];
+        nd[24 + j] = hi[j][1];
+        nd[32 + j] = lo[j][2];
+        nd[40 + j] = hi[j][2];
+        nd[48 + j] = __uint_as_float(r.handle[j]);
+        nd[56 + j] = __uint_as_float(perm[j]);
+    }
+}
+
+struct Scratch { // device allocations of one build, freed on every way out
+    std::vector<void*> ptrs;
+    ~Scratch()
+    {
+        for (void* p : ptrs)
+            (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t alloc(T** out, size_t count)
+    {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess)
+            ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+};
+
+inline uint32_t blocksFor(size_t n) { return uint32_t(std::max<size_t>(1, (n + 255) / 256)); }
+
+} // namespace
+
+extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, pgpu_host_bvh8** out, uint32_t* n_host_built)
+{
+    const TraceRange range_("pgpu_build_bvh8_device");
+    if (!c || !positions || !indices || !group_prims || !group_offsets || !out || n_groups == 0)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: null or empty argument");
+    if (max_leaf < 1 || max_leaf > 4)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: max_leaf must be 1..4");
+    if (n_groups > (1u << 20) || n_vertices > 0xFFFFFFFFull / 3 || n_triangles > 0xFFFFFFFFull / 3)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: more than 2^20 groups or 2^32 / 3 vertices / triangles");
+    const uint64_t nEntries = group_offsets[n_groups];
+    if (group_offsets[0] != 0 || nEntries == 0 || nEntries >= 0x7FFFFFFFull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: offsets must start at 0 and name 1 .. 2^31 - 2 triangles in all");
+    for (size_t g = 0; g < n_groups; ++g) {
+        if (group_offsets[g] >= group_offsets[g + 1])
+            return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: empty group (offsets must increase)");
+        if (group_offsets[g + 1] - group_offsets[g] >= (1u << 29) - 1u)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: more than 2^29 triangles in one group");
+    }
+    for (uint64_t i = 0; i < nEntries; ++i)
+        if (group_prims[i] >= n_triangles)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: primitive index out of range");
+    for (size_t i = 0; i < 3 * n_triangles; ++i)
+        if (indices[i] >= n_vertices)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: vertex index out of range");
+    for (size_t g = 0; g < n_groups; ++g)
+        out[g] = nullptr;
+    if (n_host_built)
+        *n_host_built = 0;
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = c->stream;
+    Scratch mem;
+    const uint32_t N = uint32_t(nEntries), G = uint32_t(n_groups);
+    // 14 bits per axis whatever the number of groups (2^20 at most: 62 bits in all), so that a group's tree is the same whether
+    // it is built alone or with others
+    const int bitsPerAxis = 14, groupBits = 20;
+
+    float* dPos = nullptr;
+    uint32_t *dIdx = nullptr, *dPrims = nullptr, *dGroupOf = nullptr, *dCBounds = nullptr, *dVals = nullptr, *dOrder = nullptr;
+    unsigned long long *dOffsets = nullptr, *dKeys = nullptr, *dKeysSorted = nullptr;
+    Box6 *dPrimBox = nullptr, *dNodeBox = nullptr;
+    uint32_t *dLeft = nullptr, *dRight = nullptr, *dLo = nullptr, *dHi = nullptr, *dParentInt = nullptr, *dParentLeaf = nullptr, *dVisits = nullptr;
+    uint32_t *dGroupRoot = nullptr, *dGroupNodes = nullptr, *dGroupDepth = nullptr, *dGroupFailed = nullptr, *dNodeBase = nullptr, *dInnerCount = nullptr, *dSlotStart = nullptr, *dLeafIdx = nullptr;
+    WorkItem* dQueue[2] = { nullptr, nullptr };
+    NodeRec* dRecs = nullptr;
+    HIP_TRY(c, mem.alloc(&dPos, 3 * n_vertices));
+    HIP_TRY(c, mem.alloc(&dIdx, 3 * n_triangles));
+    HIP_TRY(c, mem.alloc(&dPrims, N));
+    HIP_TRY(c, mem.alloc(&dOffsets, n_groups + 1));
+    HIP_TRY(c, mem.alloc(&dGroupOf, N));
+    HIP_TRY(c, mem.alloc(&dCBounds, 6 * n_groups));
+    HIP_TRY(c, mem.alloc(&dPrimBox, N));
+    HIP_TRY(c, mem.alloc(&dKeys, N));
+    HIP_TRY(c, mem.alloc(&dKeysSorted, N));
+    HIP_TRY(c, mem.alloc(&dVals, N));
+    HIP_TRY(c, mem.alloc(&dOrder, N));
+    HIP_TRY(c, mem.alloc(&dLeft, N));
+    HIP_TRY(c, mem.alloc(&dRight, N));
+    HIP_TRY(c, mem.alloc(&dLo, N));
+    HIP_TRY(c, mem.alloc(&dHi, N));
+    HIP_TRY(c, mem.alloc(&dParentInt, N));
+    HIP_TRY(c, mem.alloc(&dParentLeaf, N));
+    HIP_TRY(c, mem.alloc(&dVisits, N));
+    HIP_TRY(c, mem.alloc(&dNodeBox, N));
+    HIP_TRY(c, mem.alloc(&dGroupRoot, n_groups));
+    HIP_TRY(c, mem.alloc(&dGroupNodes, n_groups));
+    HIP_TRY(c, mem.alloc(&dGroupDepth, n_groups));
+    HIP_TRY(c, mem.alloc(&dGroupFailed, n_groups));
+    HIP_TRY(c, mem.alloc(&dNodeBase, n_groups));
+    HIP_TRY(c, mem.alloc(&dInnerCount, size_t(N) + 1));
+    HIP_TRY(c, mem.alloc(&dSlotStart, size_t(N) + 1));
+    HIP_TRY(c, mem.alloc(&dQueue[0], N));
+    HIP_TRY(c, mem.alloc(&dQueue[1], N));
+    HIP_TRY(c, mem.alloc(&dRecs, N));
+    HIP_TRY(c, mem.alloc(&dLeafIdx, N));
+    size_t sortBytes = 0;
+    const int endBit = std::min(64, 3 * bitsPerAxis + groupBits);
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, dKeys, dKeysSorted, dVals, dOrder, int(N), 0, endBit, stream));
+    unsigned char* dSortTemp = nullptr;
+    HIP_TRY(c, mem.alloc(&dSortTemp, sortBytes));
+    size_t scanBytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, dInnerCount, dSlotStart, int(N) + 1, stream));
+    unsigned char* dScanTemp = nullptr;
+    HIP_TRY(c, mem.alloc(&dScanTemp, scanBytes));
+
+    HIP_TRY(c, hipMemcpyAsync(dPos, positions, 3 * n_vertices * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(dIdx, indices, 3 * n_triangles * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(dPrims, group_prims, size_t(N) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(dOffsets, group_offsets, (n_groups + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    std::vector<uint32_t> boundsInit(6 * n_groups);
+    for (size_t g = 0; g < n_groups; ++g)
+        for (int a = 0; a < 3; ++a) {
+            boundsInit[6 * g + size_t(a)] = 0xFFFFFFFFu;
+            boundsInit[6 * g + 3 + size_t(a)] = 0u;
+        }
+    HIP_TRY(c, hipMemcpyAsync(dCBounds, boundsInit.data(), boundsInit.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemsetAsync(dParentInt, 0xFF, size_t(N) * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(dParentLeaf, 0xFF, size_t(N) * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(dVisits, 0, size_t(N) * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(dGroupRoot, 0xFF, n_groups * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(dGroupDepth, 0, n_groups * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(dGroupFailed, 0, n_groups * 4, stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+
+    hipLaunchKernelGGL(primBoundsKernel, dim3(blocksFor(N)), dim3(256), 0, stream, dPos, dIdx, dPrims, dOffsets, G, N, dGroupOf, dPrimBox, dCBounds);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(mortonKernel, dim3(blocksFor(N)), dim3(256), 0, stream, dPrimBox, dGroupOf, dCBounds, N, bitsPerAxis, dKeys, dVals);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dSortTemp, sortBytes, dKeys, dKeysSorted, dVals, dOrder, int(N), 0, endBit, stream));
+    if (N > 1u) {
+        hipLaunchKernelGGL(hierarchyKernel, dim3(blocksFor(N - 1u)), dim3(256), 0, stream, dKeysSorted, N, dGroupOf, dOffsets, dLeft, dRight, dLo, dHi, dParentInt,
+            dParentLeaf, dGroupRoot);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(fitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dPrimBox, dLeft, dRight, dParentInt, dParentLeaf, dVisits, dNodeBox);
+        HIP_TRY(c, hipGetLastError());
+    }
+    // seeds, in group order: the root of every group that is more than one leaf
+    std::vector<uint32_t> roots(n_groups), nodeCount(n_groups, 0u);
+    HIP_TRY(c, hipMemcpyAsync(roots.data(), dGroupRoot, n_groups * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    std::vector<WorkItem> seeds;
+    for (size_t g = 0; g < n_groups; ++g)
+        if (group_offsets[g + 1] - group_offsets[g] > max_leaf) {
+            if (roots[g] + 1u >= N)
+                return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: a group is not a subtree of the radix tree (internal error)");
+            seeds.push_back(WorkItem { roots[g], 0u, uint32_t(g) });
+            nodeCount[g] = 1u;
+        }
+    HIP_TRY(c, hipMemcpyAsync(dGroupNodes, nodeCount.data(), n_groups * 4, hipMemcpyHostToDevice, stream));
+    if (!seeds.empty())
+        HIP_TRY(c, hipMemcpyAsync(dQueue[0], seeds.data(), seeds.size() * sizeof(WorkItem), hipMemcpyHostToDevice, stream));
+    int maxLevels = kMaxLevels;
+    if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_LEVELS")) // (tests: a smaller budget sends groups to the host builder)
+        maxLevels = std::max(1, std::min(kMaxLevels, std::atoi(e)));
+    int margin = 2;
+    if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_MARGIN"))
+        margin = std::max(0, std::min(kMaxLevels, std::atoi(e)));
+    uint32_t count = uint32_t(seeds.size());
+    for (int level = 0; level < maxLevels && count != 0u; ++level) {
+        if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG"))
+            std::fprintf(stderr, "bvh_build: level %d, %u nodes\n", level, count);
+        // A child of a node at this level may root (maxLevels - 1 - level) levels of inner nodes, which hold max_leaf * 8^that
+        // triangles if every node below is full. A radix tree is not that regular: children are opened by size rather than by
+        // surface once they hold what `margin` levels fewer could (a sparse scene's largest boxes are single triangles near the
+        // root; opening by surface alone peels them off one level at a time and runs out of depth on the dense parts).
+        unsigned long long capacity = max_leaf;
+        for (int l = level + 1 + margin; l < maxLevels; ++l)
+            capacity *= 8ull;
+        hipLaunchKernelGGL(expandKernel, dim3(blocksFor(size_t(count) + 1)), dim3(256), 0, stream, dQueue[level & 1], count, uint32_t(level), uint32_t(maxLevels), max_leaf,
+            capacity, dLeft, dRight, dLo, dHi, dNodeBox, dOffsets, dRecs, dInnerCount, dGroupDepth, dGroupFailed);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dScanTemp, scanBytes, dInnerCount, dSlotStart, int(count) + 1, stream));
+        hipLaunchKernelGGL(assignKernel, dim3(blocksFor(count)), dim3(256), 0, stream, dQueue[level & 1], count, dInnerCount, dSlotStart, dOffsets, dRecs,
+            dQueue[(level + 1) & 1], dGroupNodes);
+        HIP_TRY(c, hipGetLastError());
+        uint32_t next = 0;
+        HIP_TRY(c, hipMemcpyAsync(&next, dSlotStart + count, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        if (next >= N)
+            return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: work queue overran (internal error)");
+        count = next;
+    }
+    std::vector<uint32_t> depth(n_groups), failed(n_groups), nodeBase(n_groups);
+    HIP_TRY(c, hipMemcpyAsync(nodeCount.data(), dGroupNodes, n_groups * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipMemcpyAsync(depth.data(), dGroupDepth, n_groups * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipMemcpyAsync(failed.data(), dGroupFailed, n_groups * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG")) {
+        for (size_t g = 0; g < std::min<size_t>(n_groups, 8); ++g)
+            std::fprintf(stderr, "bvh_build: group %zu: %llu triangles, root %u, %u nodes, depth %u, failed %u\n", g,
+                (unsigned long long)(group_offsets[g + 1] - group_offsets[g]), roots[g], nodeCount[g], depth[g], failed[g]);
+    }
+    uint64_t totalNodes = 0;
+    for (size_t g = 0; g < n_groups; ++g) {
+        if (nodeCount[g] >= group_offsets[g + 1] - group_offsets[g] && nodeCount[g] != 0)
+            return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: more nodes than triangles in a group (internal error)");
+        if (failed[g])
+            nodeCount[g] = 0;
+        nodeBase[g] = uint32_t(totalNodes);
+        totalNodes += nodeCount[g];
+    }
+    if (totalNodes >= 0xFFFFFFFFull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: more than 2^32 nodes in all");
+    unsigned char* dNodes = nullptr;
+    HIP_TRY(c, mem.alloc(&dNodes, size_t(totalNodes) * 256));
+    HIP_TRY(c, hipMemcpyAsync(dNodeBase, nodeBase.data(), n_groups * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(dGroupNodes, nodeCount.data(), n_groups * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(emitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dGroupOf, dOffsets, dGroupNodes, dGroupFailed, dNodeBase, dRecs, dOrder, dPrimBox, dNodeBox,
+        dNodes, dLeafIdx);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    std::vector<unsigned char> nodes(size_t(totalNodes) * 256);
+    std::vector<uint32_t> leafIdx(N);
+    if (totalNodes)
+        HIP_TRY(c, hipMemcpyAsync(nodes.data(), dNodes, nodes.size(), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipMemcpyAsync(leafIdx.data(), dLeafIdx, size_t(N) * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
+    c->timingStale = false;
+
+    uint32_t hostBuilt = 0;
+    int rc = PGPU_OK;
+    for (size_t g = 0; g < n_groups && rc == PGPU_OK; ++g) {
+        const size_t first = size_t(group_offsets[g]), count = size_t(group_offsets[g + 1] - group_offsets[g]);
+        if (failed[g]) {
+            ++hostBuilt;
+            rc = pgpu_build_bvh8(positions, n_vertices, indices, n_triangles, group_prims + first, count, max_leaf, &out[g]);
+            if (rc != PGPU_OK)
+                c->err = "pgpu_build_bvh8_device: the host builder failed on a group the device tree was too deep for";
+            continue;
+        }
+        const uint32_t root = count <= max_leaf ? ((uint32_t(count) - 1u) | 4u) << 29 : (2u << 29);
+        out[g] = makeHostBvh8(nodes.data() + size_t(nodeBase[g]) * 256, nodeCount[g], leafIdx.data() + first, count, root, int(depth[g]));
+        if (!out[g])
+            rc = fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: out of host memory");
+    }
+    if (rc != PGPU_OK) {
+        for (size_t g = 0; g < n_groups; ++g)
+            if (out[g]) {
+                pgpu_host_bvh8_free(out[g]);
+                out[g] = nullptr;
+            }
+        return rc;
+    }
+    if (n_host_built)
+        *n_host_built = hostBuilt;
+    return PGPU_OK;
+}

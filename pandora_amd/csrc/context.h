@@ -136,6 +136,8 @@ struct pgpu_ctx {
 
 struct pgpu_host_svdags;
 namespace pandora_hip {
+// wraps finished node / leaf-index arrays as the object pgpu_build_bvh8 returns (pandora_amd/host/bvh_builder.cpp)
+pgpu_host_bvh8* makeHostBvh8(const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices, uint32_t root, int depth);
 // wraps a finished DAG array as the object pgpu_build_svdags returns (pandora_amd/host/svdag_builder.cpp)
 pgpu_host_svdags* makeHostSvdags(std::vector<uint32_t>&& words, std::vector<pgpu_svdag_desc>&& descs, size_t wordsBeforeCompression);
 // Shared by every translation unit of the C ABI (defined in abi.hip).

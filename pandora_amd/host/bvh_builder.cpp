@@ -18,6 +18,7 @@
 #include <cfloat>
 #include <condition_variable>
 #include <mutex>
+#include <new>
 #include <cstdlib>
 #include <thread>
 #include <cmath>
@@ -875,5 +876,22 @@ int pgpu_partition_objects(const float* bounds6, const uint64_t* weights, size_t
     }
     *n_groups = g;
     return PGPU_OK;
+}
+}
+
+namespace pandora_hip {
+// wraps finished arrays (the device builder's, pandora_amd/csrc/bvh_build.hip) as the object pgpu_build_bvh8 returns
+pgpu_host_bvh8* makeHostBvh8(const void* nodes256, size_t n_nodes, const uint32_t* leaf_indices, size_t n_indices, uint32_t root, int depth)
+{
+    auto* r = new (std::nothrow) pgpu_host_bvh8();
+    if (!r)
+        return nullptr;
+    r->v.nodes.resize(n_nodes);
+    if (n_nodes)
+        std::memcpy(r->v.nodes.data(), nodes256, n_nodes * sizeof(Node8));
+    r->v.leafIdx.assign(leaf_indices, leaf_indices + n_indices);
+    r->v.root = root;
+    r->v.depth = depth;
+    return r;
 }
 }

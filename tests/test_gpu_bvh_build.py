@@ -1,0 +1,185 @@
+"""pgpu_build_bvh8_device (pandora_amd/csrc/bvh_build.hip): the BVH8s of many batching points built on the GPU. Topology is the
+builder's own (as the host builder's: the reference's comes from Embree), so the checks are the structural invariants of the
+reference's layout, the octant words against the oracle's restatement of wive_bvh8_build8_impl.h:172-203, and traces through the
+device-built trees: bit-exact against the oracle on the same tree, same nearest distance as through the host builder's tree."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pandora_amd as pa
+
+pytestmark = pytest.mark.gpu
+MISS = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pa.accel.Context(0)
+    yield c
+    c.close()
+
+
+def check_tree(hb, mesh, max_leaf):
+    """Every triangle of the group exactly once, handles in range, children packed at the front, stored child boxes equal to the
+    exact bounds below them, absent children zero, octant words by the reference's rule. -> depth"""
+    nu = hb.nodes.view(np.uint32)
+    tri_lo = mesh.pos[mesh.idx].min(axis=1)
+    tri_hi = mesh.pos[mesh.idx].max(axis=1)
+    seen_nodes, slots = set(), []
+    lo_of, hi_of = {}, {}
+    order = []
+    stack = [(hb.root, 0)]
+    depth = 0
+    while stack:
+        h, d = stack.pop()
+        flags, i = h >> 29, h & 0x1FFFFFFF
+        if flags == 2:
+            assert i < hb.n_nodes and i not in seen_nodes
+            seen_nodes.add(i)
+            order.append(i)
+            depth = max(depth, d + 1)
+            k = int((nu[i, 48:56] != 0).sum())
+            assert k >= 2 and np.all(nu[i, 48:48 + k] != 0), "children are packed at the front"
+            assert np.all(hb.nodes[i, 0:48].reshape(6, 8)[:, k:] == 0), "absent children are zero boxes"
+            for c in range(k):
+                stack.append((int(nu[i, 48 + c]), d + 1))
+        else:
+            assert flags & 4, "reserved handle flags"
+            cnt = (flags & 3) + 1
+            assert cnt <= max_leaf and i + cnt <= hb.leaf_idx.size
+            slots.extend(range(i, i + cnt))
+    assert len(seen_nodes) == hb.n_nodes
+    assert sorted(slots) == list(range(hb.leaf_idx.size))
+    assert sorted(hb.leaf_idx.tolist()) == list(range(hb.prim_ids.size))
+    assert depth == hb.depth and 7 * depth + 8 <= 96
+
+    def leaf_bounds(h):
+        i, cnt = h & 0x1FFFFFFF, ((h >> 29) & 3) + 1
+        prims = hb.prim_ids[hb.leaf_idx[i:i + cnt]]
+        return tri_lo[prims].min(axis=0), tri_hi[prims].max(axis=0)
+
+    for i in reversed(order):  # children before parents (a parent is pushed before its children)
+        n = hb.nodes[i]
+        k = int((nu[i, 48:56] != 0).sum())
+        los, his = [], []
+        for c in range(k):
+            h = int(nu[i, 48 + c])
+            lo, hi = (lo_of[h & 0x1FFFFFFF], hi_of[h & 0x1FFFFFFF]) if (h >> 29) == 2 else leaf_bounds(h)
+            assert np.array_equal(np.array([n[c], n[16 + c], n[32 + c]], np.float32), lo.astype(np.float32)), (i, c)
+            assert np.array_equal(np.array([n[8 + c], n[24 + c], n[40 + c]], np.float32), hi.astype(np.float32)), (i, c)
+            los.append(lo)
+            his.append(hi)
+        lo_of[i], hi_of[i] = np.min(los, axis=0), np.max(his, axis=0)
+        blo = np.ascontiguousarray(np.stack([n[0:8], n[16:24], n[32:40]], 1), np.float32)
+        bhi = np.ascontiguousarray(np.stack([n[8:16], n[24:32], n[40:48]], 1), np.float32)
+        want = np.zeros(8, np.uint32)
+        ob.oracle().orc_bvh8_perm(blo.ctypes.data, bhi.ctypes.data, k, want.ctypes.data)
+        assert np.array_equal(nu[i, 56:64], want), i
+    return depth
+
+
+@pytest.mark.parametrize("max_leaf", [1, 4])
+def test_device_built_tree_has_the_reference_layout(ctx, max_leaf):
+    mesh = pa.scenes.g_small()
+    (hb,), host_built = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, None, max_leaf=max_leaf)
+    assert host_built == 0
+    check_tree(hb, mesh, max_leaf)
+
+
+def test_traces_through_a_device_built_tree_match_the_oracle_and_the_host_tree(ctx):
+    mesh = pa.scenes.g_atrium(40_000)
+    (hb,), host_built = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx)
+    assert host_built == 0
+    check_tree(hb, mesh, 4)
+    host = pa.accel.build_bvh8(mesh.pos, mesh.idx)
+    rays = pa.scenes.primary_rays((3, 3, 9), (28, 5, 9), (0, 1, 0), 70, 192, 192)
+    rays = np.concatenate([rays, pa.scenes.random_rays(mesh.pos.min(0), mesh.pos.max(0), 30_000, seed=5)], axis=1)
+    mid = ctx.upload_mesh(mesh.pos, mesh.idx)
+    got = ctx.trace_bvh8(ctx.upload_bvh8(hb, mid), rays)
+    want = ob.OracleBvh8.from_host(hb, mesh).trace(rays)
+    for k in ("t", "obj", "u", "v"):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    ref = ob.OracleBvh8.from_host(host, mesh).trace(rays)
+    # The nearest distance does not depend on the tree but for a handful of rays that differ in the last bits: two triangles an
+    # ulp apart along the ray, and a node whose entry distance equals the current hit distance is skipped -- which of the two is
+    # seen first depends on the tree (tests/test_builder.py compares the host builder's two constructions the same way).
+    differ = np.nonzero(got["t"].view(np.uint32) != ref["t"].view(np.uint32))[0]
+    assert differ.size <= 2e-4 * rays.shape[1], differ.size
+    assert np.allclose(got["t"][differ], ref["t"][differ], rtol=1e-5, atol=0)
+    any_got = ctx.trace_bvh8(ctx.upload_bvh8(hb, mid), rays, kind=pa.capi.ANY)["hit"]
+    any_ref = ob.OracleBvh8.from_host(host, mesh).trace(rays, any_hit=True)["hit"]
+    assert np.array_equal(any_got, ob.OracleBvh8.from_host(hb, mesh).trace(rays, any_hit=True)["hit"])
+    assert np.count_nonzero(any_got != any_ref) <= 2e-4 * rays.shape[1]
+    # quality: what a ray pays in this tree against the host builder's (binary SAH tree collapsed by dynamic programming)
+    cd, ch = want["counters"], ref["counters"]
+    assert cd["inner_visits"] < 1.6 * ch["inner_visits"], (cd, ch)
+
+
+def test_many_groups_in_one_build_and_a_two_level_scene_on_them(ctx):
+    mesh = pa.scenes.g_city(4, 6000)
+    group_of, ng = pa.accel.partition_prims(mesh.pos, mesh.idx, 4000)
+    groups = [np.nonzero(group_of == g)[0].astype(np.uint32) for g in range(ng)]
+    assert ng > 8
+    bvhs, host_built = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, groups)
+    assert host_built == 0 and len(bvhs) == ng
+    for hb, g in zip(bvhs, groups):
+        assert np.array_equal(hb.prim_ids, g)
+        check_tree(hb, mesh, 4)
+    # the same groups one at a time give the same trees (a group's tree does not depend on its neighbours in the build)
+    for gi in (0, ng // 2, ng - 1):
+        (alone,), _ = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, [groups[gi]])
+        assert np.array_equal(alone.nodes.view(np.uint32), bvhs[gi].nodes.view(np.uint32)) and np.array_equal(alone.leaf_idx, bvhs[gi].leaf_idx)
+    c2 = pa.accel.Context(0)
+    try:
+        tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 4000, svdag_res=16, bvh_device_ctx=c2, svdag_device_ctx=c2)
+        tl.upload(c2, c2.upload_mesh(mesh.pos, mesh.idx))
+        lo, hi = mesh.pos.min(0), mesh.pos.max(0)
+        rays = pa.scenes.random_rays(lo, hi, 60_000, seed=9)
+        got, cnt = c2.trace(rays)
+        want = ob.scene_from_two_level(tl, mesh).trace(rays)
+        for k in ("t", "obj", "leaf", "u", "v", "visits"):
+            assert np.array_equal(np.asarray(got[k]).view(np.uint32), want[k].view(np.uint32)), k
+        assert (want["obj"].view(np.uint32) != MISS).mean() > 0.3
+    finally:
+        c2.close()
+
+
+def test_degenerate_groups(ctx):
+    rng = np.random.default_rng(3)
+    # 5000 coincident triangles (every key equal: the positions break the ties, the tree is balanced), a single triangle,
+    # three triangles (the root is a leaf handle), and a sliver of triangles along one axis
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    pos = [np.tile(tri, (5000, 1)), tri + 5, np.tile(tri, (3, 1)) + np.repeat(np.arange(3, dtype=np.float32), 3)[:, None] * 2 + 10]
+    line = np.tile(tri * 1e-3, (700, 1))
+    line[:, 0] += np.repeat(rng.uniform(0, 100, 700).astype(np.float32), 3)
+    pos.append(line)
+    pos = np.concatenate(pos).astype(np.float32)
+    idx = np.arange(pos.shape[0], dtype=np.uint32).reshape(-1, 3)
+    counts = [5000, 1, 3, 700]
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    groups = [np.arange(starts[i], starts[i + 1], dtype=np.uint32) for i in range(4)]
+    mesh = pa.scenes.Mesh(pos, idx)
+    bvhs, host_built = pa.accel.build_bvh8_device(ctx, pos, idx, groups)
+    assert host_built == 0
+    for hb in bvhs:
+        check_tree(hb, mesh, 4)
+    assert bvhs[1].n_nodes == 0 and bvhs[1].root >> 29 == 4 and bvhs[2].n_nodes == 0 and bvhs[2].root >> 29 == 6
+    assert bvhs[0].depth <= 6  # 5000 equal keys: 1250 leaves of four under a balanced tree
+    with pytest.raises(pa.capi.PandoraError):
+        pa.accel.build_bvh8_device(ctx, pos, idx, [np.array([idx.shape[0]], np.uint32)])  # triangle out of range
+    with pytest.raises(pa.capi.PandoraError):
+        pa.accel.build_bvh8_device(ctx, pos, idx, [groups[0], np.zeros(0, np.uint32)])  # empty group
+
+
+def test_groups_too_deep_for_the_stack_go_to_the_host_builder(ctx, monkeypatch):
+    mesh = pa.scenes.g_small()
+    half = mesh.n_tris // 2
+    groups = [np.arange(0, half, dtype=np.uint32), np.arange(half, mesh.n_tris, dtype=np.uint32), np.arange(0, 30, dtype=np.uint32)]
+    monkeypatch.setenv("PANDORA_BVH8_DEVICE_LEVELS", "2")  # 2 levels hold 4 * 8 * 8 = 256 triangles at most
+    bvhs, host_built = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, groups)
+    assert host_built == 2 and bvhs[2].depth <= 2
+    for hb, g in zip(bvhs, groups):
+        assert np.array_equal(hb.prim_ids, g)
+        check_tree(hb, mesh, 4)
+    host = pa.accel.build_bvh8(mesh.pos, mesh.idx, groups[0])
+    assert np.array_equal(host.nodes.view(np.uint32), bvhs[0].nodes.view(np.uint32)) and np.array_equal(host.leaf_idx, bvhs[0].leaf_idx)
