@@ -73,6 +73,17 @@ void pgpu_host_bvh8_free(pgpu_host_bvh8*);
 int pgpu_build_bvh8_device(pgpu_ctx*, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
     const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, pgpu_host_bvh8** out,
     uint32_t* n_host_built);
+/* The same build with the trees left where they were made (needs no pgpu_upload_mesh): nodes, 48-byte triangle records and, with
+ * pgpu_set_keep_shading, the vertices per leaf object stay in HBM and join the context's BVH table as if pgpu_upload_bvh8 had been
+ * called for every group with leaf objects (mesh, group_prims[j]); bvh_ids[g] receives group g's id. Nothing of the trees crosses
+ * PCIe. A group too deep for the device builder is built by pgpu_build_bvh8 and uploaded. */
+int pgpu_build_upload_bvh8_device(pgpu_ctx*, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, uint32_t* bvh_ids,
+    uint32_t* n_host_built);
+/* A BVH of the context (resident or staged) back in the arrays pgpu_upload_bvh8 takes: sizes first, then nodes256 (n_nodes x 256
+ * bytes) and leaf_indices (n_indices words). For trees built on the device, for checks, and for pgpu_bvh8_serialize. */
+int pgpu_bvh8_info(pgpu_ctx*, uint32_t bvh_id, size_t* n_nodes, size_t* n_indices, uint32_t* root_handle, int* depth);
+int pgpu_download_bvh8(pgpu_ctx*, uint32_t bvh_id, void* nodes256, uint32_t* leaf_indices);
 /* BVH8 over arbitrary leaf objects given by their bounds (n_objects x {min xyz, max xyz}); leaf object j = box j. An object
  * with alone[j] != 0 gets a leaf of its own (instances; alone may be NULL). What LRUBVHSceneCache::createBVH builds over
  * the mix of instanced sub-scenes and triangles of a sub-scene (offline_bvh_cache.cpp:273-309). */

@@ -414,6 +414,31 @@ class Context:
                                         objs.ctypes.data, objs.shape[0], C.byref(out)), self._h)
         return int(out.value)
 
+    def build_upload_bvh8_device(self, pos, idx, groups: "list[np.ndarray] | None" = None, max_leaf: int = 4):
+        """pgpu_build_upload_bvh8_device: the BVH8s of the triangle groups built on this GPU and left there, as part of the context's
+        BVH table (no upload_mesh / upload_bvh8). -> (bvh ids, groups the host builder had to take)."""
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+        if groups is None:
+            groups = [np.arange(idx.shape[0], dtype=np.uint32)]
+        offsets = np.zeros(len(groups) + 1, np.uint64)
+        offsets[1:] = np.cumsum([np.asarray(g).size for g in groups])
+        prims = np.ascontiguousarray(np.concatenate(groups), np.uint32)
+        ids = np.zeros(len(groups), np.uint32)
+        host_built = C.c_uint32()
+        _check(self._L.pgpu_build_upload_bvh8_device(self._h, pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], prims.ctypes.data, offsets.ctypes.data,
+                                                     len(groups), max_leaf, ids.ctypes.data, C.byref(host_built)), self._h)
+        return ids, int(host_built.value)
+
+    def download_bvh8(self, bvh_id: int, prim_ids: np.ndarray) -> HostBvh8:
+        """A BVH of this context back as a HostBvh8 (pgpu_download_bvh8); prim_ids = its leaf objects' triangle ids."""
+        nn, ni, root, depth = C.c_size_t(), C.c_size_t(), C.c_uint32(), C.c_int()
+        _check(self._L.pgpu_bvh8_info(self._h, int(bvh_id), C.byref(nn), C.byref(ni), C.byref(root), C.byref(depth)), self._h)
+        nodes = np.zeros((nn.value, 64), np.float32)
+        leaf_idx = np.zeros(ni.value, np.uint32)
+        _check(self._L.pgpu_download_bvh8(self._h, int(bvh_id), nodes.ctypes.data if nn.value else None, leaf_idx.ctypes.data), self._h)
+        return HostBvh8(nodes, leaf_idx, int(root.value), int(depth.value), np.ascontiguousarray(prim_ids, np.uint32))
+
     def stage_bvh8(self, bvh: HostBvh8, mesh_id: int) -> int:
         """Like upload_bvh8, but the BVH stays in pinned host memory and is streamed into the HBM leaf cache on demand."""
         objs = np.empty((bvh.prim_ids.size, 2), np.uint32)
@@ -753,10 +778,17 @@ class TwoLevelScene:
     top: HostBvh4
     dags: HostSvdags | None
     leaf_bounds: np.ndarray
+    bvh_ids: "np.ndarray | None" = None  # per input leaf: the id of its BVH8 when the trees were built on (and never left) a context's GPU
 
     @property
     def n_leaves(self) -> int:
         return len(self.groups)
+
+    def fetch_bvhs(self, ctx: "Context"):
+        """Trees that were built on the device (build_two_level(..., resident_ctx=ctx)) brought back as HostBvh8s, for the oracle
+        and the on-disk format."""
+        self.bvhs = [ctx.download_bvh8(int(i), g) if int(i) != capi.NO_BVH else None for i, g in zip(self.bvh_ids, self.groups)]
+        return self
 
     def prim_ids_of(self, leaf: np.ndarray, obj: np.ndarray) -> np.ndarray:
         """Mesh triangle id of every hit record (leaf slot, leaf-object index); MISS stays MISS."""
@@ -805,7 +837,12 @@ class TwoLevelScene:
         if prim_remap is not None and streamed:
             raise ValueError("prim_remap is for resident uploads")
         put = ctx.stage_bvh8 if streamed else (lambda b, m: ctx.upload_bvh8(b, m, prim_remap))  # streamed: leaves live in pinned host memory (config 5)
-        ids = [put(b, mesh_id) if (b is not None and (resident is None or bool(resident[slot_of[i]]))) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
+        if self.bvh_ids is not None:  # built on this context's GPU and already part of its BVH table
+            if streamed or resident is not None:
+                raise ValueError("trees built on the device are resident as they are")
+            ids = [int(i) for i in self.bvh_ids]
+        else:
+            ids = [put(b, mesh_id) if (b is not None and (resident is None or bool(resident[slot_of[i]]))) else capi.NO_BVH for i, b in enumerate(self.bvhs)]
         if self.dags is not None:
             ctx.upload_svdags(self.dags)
         leaves = np.empty((self.n_leaves, 2), np.uint32)
@@ -817,11 +854,14 @@ class TwoLevelScene:
 
 
 def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4, build_group=None,
-                    svdag_device_ctx: "Context | None" = None, bvh_device_ctx: "Context | None" = None) -> TwoLevelScene:
+                    svdag_device_ctx: "Context | None" = None, bvh_device_ctx: "Context | None" = None, resident_ctx: "Context | None" = None) -> TwoLevelScene:
     """build_group: optional callable (group sizes: int array[, top: HostBvh4]) -> bool array; only those batching points get a
     bottom-level BVH8 here (the others stay None: they live on another rank). A callable that takes two arguments also gets the
     top level, which is built first (from the groups' bounds) so that ownership can follow its leaf order. The cut, the top
-    level and the SVDAGs are always whole. svdag_device_ctx: build the SVDAGs on that context's GPU instead of the host."""
+    level and the SVDAGs are always whole. svdag_device_ctx: build the SVDAGs on that context's GPU instead of the host;
+    bvh_device_ctx: likewise the bottom-level BVH8s (LBVH quality, see pgpu_build_bvh8_device); resident_ctx: the BVH8s are built on
+    that context's GPU and stay there (pgpu_build_upload_bvh8_device: `bvh_ids` instead of `bvhs`; upload() then only adds the
+    SVDAGs and the top level, fetch_bvhs() brings the trees back when the host wants them)."""
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
     group_of, ng = partition_prims(pos, idx, prims_per_batching_point)
@@ -829,11 +869,14 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     counts = np.bincount(group_of, minlength=ng)
     starts = np.concatenate([[0], np.cumsum(counts)])
     groups = [np.ascontiguousarray(order[starts[g]:starts[g + 1]]) for g in range(ng)]
+    # bounds per group: the triangles' own bounds reduced over the groups laid end to end (one pass instead of a gather per group)
+    tri = pos[idx[order]]  # (n, 3 vertices, 3)
     bounds = np.empty((ng, 6), np.float32)
-    for g, prims in enumerate(groups):
-        v = pos[idx[prims].ravel()]
-        bounds[g, :3] = v.min(axis=0)
-        bounds[g, 3:] = v.max(axis=0)
+    nonempty = counts > 0
+    at = starts[:-1][nonempty]
+    bounds[nonempty, :3] = np.minimum.reduceat(tri.min(axis=1), at, axis=0)
+    bounds[nonempty, 3:] = np.maximum.reduceat(tri.max(axis=1), at, axis=0)
+    del tri
     top = build_top_bvh4(bounds)
     # the per-group builds are independent C calls (ctypes releases the GIL): run them on a few threads
     workers = max(1, min(host_threads(), len(groups)))
@@ -844,7 +887,14 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
         two = len(inspect.signature(build_group).parameters) >= 2
         want = np.asarray(build_group(counts, top) if two else build_group(counts), bool)
     build = lambda gi: build_bvh8(pos, idx, groups[gi], max_leaf) if want[gi] else None
-    if bvh_device_ctx is not None:  # every wanted batching point's BVH8 in one pass over the GPU (pgpu_build_bvh8_device)
+    bvh_ids = None
+    if resident_ctx is not None:
+        sel = [gi for gi in range(ng) if want[gi]]
+        ids, _ = resident_ctx.build_upload_bvh8_device(pos, idx, [groups[gi] for gi in sel], max_leaf) if sel else (np.zeros(0, np.uint32), 0)
+        bvh_ids = np.full(ng, capi.NO_BVH, np.uint32)
+        bvh_ids[sel] = ids
+        bvhs = [None] * ng
+    elif bvh_device_ctx is not None:  # every wanted batching point's BVH8 in one pass over the GPU (pgpu_build_bvh8_device)
         sel = [gi for gi in range(ng) if want[gi]]
         built, _ = build_bvh8_device(bvh_device_ctx, pos, idx, [groups[gi] for gi in sel], max_leaf) if sel else ([], 0)
         bvhs = [None] * ng
@@ -857,7 +907,7 @@ def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0,
     else:
         bvhs = [build(gi) for gi in range(ng)]
     dags = build_svdags(pos, idx, groups, svdag_res, device_ctx=svdag_device_ctx) if svdag_res > 0 else None
-    return TwoLevelScene(groups, bvhs, top, dags, bounds)
+    return TwoLevelScene(groups, bvhs, top, dags, bounds, bvh_ids)
 
 
 def svdags_concat(parts: list) -> "tuple[np.ndarray, list[np.ndarray]]":

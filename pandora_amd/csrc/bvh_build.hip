@@ -448,6 +448,35 @@ __global__ void __launch_bounds__(256) emitKernel(uint32_t n, const uint32_t* __
     }
 }
 
+// ---- 7. (pgpu_build_upload_bvh8_device) the 48-byte triangle records of the trees, slot by slot: what pgpu_upload_bvh8 gathers on
+// the host (Bvh8Dev in kernels.h). Group g's records start g records further than its slots (one zero record of padding behind
+// every group: the pair-layout kernel reads records two at a time). shade (optional): the vertices per leaf object.
+__global__ void __launch_bounds__(256) triRecordsKernel(uint32_t n, const float* __restrict__ pos, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ prims,
+    const unsigned long long* __restrict__ offsets, const uint32_t* __restrict__ groupOf, const uint32_t* __restrict__ leafIdx, float* __restrict__ tris,
+    float* __restrict__ shade, uint32_t* __restrict__ groupNonFinite)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint32_t g = groupOf[p], j = leafIdx[p];
+    const size_t base = size_t(offsets[g]);
+    const uint32_t prim = prims[base + j];
+    float* const t = tris + (size_t(p) + g) * 12u;
+    bool finite = true;
+    for (int k = 0; k < 3; ++k) {
+        const float* v = pos + 3u * size_t(idx[3u * size_t(prim) + k]);
+        for (int a = 0; a < 3; ++a) {
+            t[4 * k + a] = v[a];
+            finite = finite && fabsf(v[a]) <= 3.4028234663852886e38f;
+            if (shade)
+                shade[(base + j) * 9u + 3u * k + a] = v[a];
+        }
+        t[4 * k + 3] = k == 0 ? __uint_as_float(j) : 0.0f;
+    }
+    if (!finite)
+        groupNonFinite[g] = 1u; // (its boxes may be unordered or infinite: the x86-exact slab test, Bvh8Dev::needs_exact)
+}
+
 struct Scratch { // device allocations of one build, freed on every way out
     std::vector<void*> ptrs;
     ~Scratch()
@@ -469,13 +498,22 @@ struct Scratch { // device allocations of one build, freed on every way out
 
 inline uint32_t blocksFor(size_t n) { return uint32_t(std::max<size_t>(1, (n + 255) / 256)); }
 
-} // namespace
+struct DeviceBuild { // what a build leaves on the device (freed with the object, but for dNodes when the caller asked to keep them)
+    Scratch mem;
+    uint32_t N = 0;
+    uint64_t totalNodes = 0;
+    float* dPos = nullptr;
+    uint32_t *dIdx = nullptr, *dPrims = nullptr, *dGroupOf = nullptr, *dLeafIdx = nullptr;
+    unsigned long long* dOffsets = nullptr;
+    unsigned char* dNodes = nullptr; // every group's nodes, group after group (nodeBase[g] = a group's first)
+    std::vector<uint32_t> nodeCount, depth, failed, nodeBase;
+};
 
-extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
-    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, pgpu_host_bvh8** out, uint32_t* n_host_built)
+// Validates the arguments and runs steps 1-6; ev0 is recorded behind the uploads (the caller records ev1).
+int buildOnDevice(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles, const uint32_t* group_prims,
+    const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, bool persistentNodes, DeviceBuild& b)
 {
-    const TraceRange range_("pgpu_build_bvh8_device");
-    if (!c || !positions || !indices || !group_prims || !group_offsets || !out || n_groups == 0)
+    if (!c || !positions || !indices || !group_prims || !group_offsets || n_groups == 0)
         return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: null or empty argument");
     if (max_leaf < 1 || max_leaf > 4)
         return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: max_leaf must be 1..4");
@@ -496,14 +534,9 @@ extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_
     for (size_t i = 0; i < 3 * n_triangles; ++i)
         if (indices[i] >= n_vertices)
             return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: vertex index out of range");
-    for (size_t g = 0; g < n_groups; ++g)
-        out[g] = nullptr;
-    if (n_host_built)
-        *n_host_built = 0;
-
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t stream = c->stream;
-    Scratch mem;
+    Scratch& mem = b.mem;
     const uint32_t N = uint32_t(nEntries), G = uint32_t(n_groups);
     // 14 bits per axis whatever the number of groups (2^20 at most: 62 bits in all), so that a group's tree is the same whether
     // it is built alone or with others
@@ -589,7 +622,9 @@ extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_
         HIP_TRY(c, hipGetLastError());
     }
     // seeds, in group order: the root of every group that is more than one leaf
-    std::vector<uint32_t> roots(n_groups), nodeCount(n_groups, 0u);
+    std::vector<uint32_t> roots(n_groups);
+    std::vector<uint32_t>& nodeCount = b.nodeCount;
+    nodeCount.assign(n_groups, 0u);
     HIP_TRY(c, hipMemcpyAsync(roots.data(), dGroupRoot, n_groups * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipStreamSynchronize(stream));
     std::vector<WorkItem> seeds;
@@ -634,7 +669,10 @@ extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_
             return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: work queue overran (internal error)");
         count = next;
     }
-    std::vector<uint32_t> depth(n_groups), failed(n_groups), nodeBase(n_groups);
+    std::vector<uint32_t>&depth = b.depth, &failed = b.failed, &nodeBase = b.nodeBase;
+    depth.assign(n_groups, 0u);
+    failed.assign(n_groups, 0u);
+    nodeBase.assign(n_groups, 0u);
     HIP_TRY(c, hipMemcpyAsync(nodeCount.data(), dGroupNodes, n_groups * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipMemcpyAsync(depth.data(), dGroupDepth, n_groups * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(c, hipMemcpyAsync(failed.data(), dGroupFailed, n_groups * 4, hipMemcpyDeviceToHost, stream));
@@ -656,12 +694,53 @@ extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_
     if (totalNodes >= 0xFFFFFFFFull)
         return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: more than 2^32 nodes in all");
     unsigned char* dNodes = nullptr;
-    HIP_TRY(c, mem.alloc(&dNodes, size_t(totalNodes) * 256));
+    if (persistentNodes) { // (the caller's from here on: it becomes part of the scene)
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&dNodes), std::max<size_t>(size_t(totalNodes) * 256, 256)));
+        b.dNodes = dNodes;
+    } else {
+        HIP_TRY(c, mem.alloc(&dNodes, size_t(totalNodes) * 256));
+    }
     HIP_TRY(c, hipMemcpyAsync(dNodeBase, nodeBase.data(), n_groups * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(c, hipMemcpyAsync(dGroupNodes, nodeCount.data(), n_groups * 4, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(emitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dGroupOf, dOffsets, dGroupNodes, dGroupFailed, dNodeBase, dRecs, dOrder, dPrimBox, dNodeBox,
         dNodes, dLeafIdx);
     HIP_TRY(c, hipGetLastError());
+    b.N = N;
+    b.totalNodes = totalNodes;
+    b.dPos = dPos;
+    b.dIdx = dIdx;
+    b.dPrims = dPrims;
+    b.dOffsets = dOffsets;
+    b.dGroupOf = dGroupOf;
+    b.dLeafIdx = dLeafIdx;
+    b.dNodes = dNodes;
+    return PGPU_OK;
+}
+
+} // namespace
+
+extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, pgpu_host_bvh8** out, uint32_t* n_host_built)
+{
+    const TraceRange range_("pgpu_build_bvh8_device");
+    if (!out)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_build_bvh8_device: null argument");
+    if (n_host_built)
+        *n_host_built = 0;
+    DeviceBuild b;
+    {
+        const int rb = buildOnDevice(c, positions, n_vertices, indices, n_triangles, group_prims, group_offsets, n_groups, max_leaf, false, b);
+        if (rb != PGPU_OK)
+            return rb;
+    }
+    for (size_t g = 0; g < n_groups; ++g)
+        out[g] = nullptr;
+    hipStream_t stream = c->stream;
+    const uint32_t N = b.N;
+    const uint64_t totalNodes = b.totalNodes;
+    unsigned char* const dNodes = b.dNodes;
+    uint32_t* const dLeafIdx = b.dLeafIdx;
+    const std::vector<uint32_t>&nodeCount = b.nodeCount, &depth = b.depth, &failed = b.failed, &nodeBase = b.nodeBase;
     HIP_TRY(c, hipEventRecord(c->ev1, stream));
     std::vector<unsigned char> nodes(size_t(totalNodes) * 256);
     std::vector<uint32_t> leafIdx(N);
@@ -698,5 +777,168 @@ extern "C" int pgpu_build_bvh8_device(pgpu_ctx* c, const float* positions, size_
     }
     if (n_host_built)
         *n_host_built = hostBuilt;
+    return PGPU_OK;
+}
+
+// The same build with the trees left where they were made: nodes, triangle records (and, with pgpu_set_keep_shading, the vertices per
+// leaf object) stay in HBM and join the context's BVH table as if pgpu_upload_bvh8 had been called per group with leaf objects
+// (mesh, group_prims[j]) -- nothing of them crosses PCIe.
+extern "C" int pgpu_build_upload_bvh8_device(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, uint32_t* bvh_ids, uint32_t* n_host_built)
+{
+    const TraceRange range_("pgpu_build_upload_bvh8_device");
+    if (!bvh_ids)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_build_upload_bvh8_device: null argument");
+    if (n_host_built)
+        *n_host_built = 0;
+    DeviceBuild b;
+    {
+        const int rb = buildOnDevice(c, positions, n_vertices, indices, n_triangles, group_prims, group_offsets, n_groups, max_leaf, true, b);
+        if (rb != PGPU_OK) {
+            if (b.dNodes)
+                (void)hipFree(b.dNodes);
+            return rb;
+        }
+    }
+    c->owned.push_back(b.dNodes); // (from here on the context frees it)
+    hipStream_t stream = c->stream;
+    const uint32_t N = b.N, G = uint32_t(n_groups);
+    float *dTris = nullptr, *dShade = nullptr;
+    uint32_t* dNonFinite = nullptr;
+    const size_t triFloats = (size_t(N) + G) * 12u;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&dTris), triFloats * sizeof(float)));
+    c->owned.push_back(dTris);
+    if (c->keepShading) {
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&dShade), size_t(N) * 9u * sizeof(float)));
+        c->owned.push_back(dShade);
+    }
+    HIP_TRY(c, b.mem.alloc(&dNonFinite, n_groups));
+    HIP_TRY(c, hipMemsetAsync(dTris, 0, triFloats * sizeof(float), stream));
+    HIP_TRY(c, hipMemsetAsync(dNonFinite, 0, n_groups * 4, stream));
+    hipLaunchKernelGGL(triRecordsKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, b.dPos, b.dIdx, b.dPrims, b.dOffsets, b.dGroupOf, b.dLeafIdx, dTris, dShade, dNonFinite);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    std::vector<uint32_t> nonFinite(n_groups);
+    HIP_TRY(c, hipMemcpyAsync(nonFinite.data(), dNonFinite, n_groups * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
+    c->timingStale = false;
+
+    uint32_t hostBuilt = 0;
+    const size_t firstId = c->bvhs.size();
+    int rc = PGPU_OK;
+    for (size_t g = 0; g < n_groups && rc == PGPU_OK; ++g) {
+        const size_t first = size_t(group_offsets[g]), count = size_t(group_offsets[g + 1] - group_offsets[g]);
+        Bvh8Dev d {};
+        d.n_slots = uint32_t(count);
+        d.needs_exact = nonFinite[g];
+        d.shade = dShade ? dShade + first * 9u : nullptr;
+        if (!b.failed[g]) {
+            d.nodes = b.dNodes + size_t(b.nodeBase[g]) * 256u;
+            d.tris = reinterpret_cast<const unsigned char*>(dTris + (first + g) * 12u);
+            d.root = count <= max_leaf ? ((uint32_t(count) - 1u) | 4u) << 29 : (2u << 29);
+            d.n_nodes = b.nodeCount[g];
+            d.depth = b.depth[g];
+        } else {
+            // too deep for the traversal stack: the host builder's tree, its nodes and records uploaded apart (the shade array
+            // is indexed by leaf object and already filled)
+            ++hostBuilt;
+            pgpu_host_bvh8* hb = nullptr;
+            rc = pgpu_build_bvh8(positions, n_vertices, indices, n_triangles, group_prims + first, count, max_leaf, &hb);
+            if (rc != PGPU_OK) {
+                c->err = "pgpu_build_upload_bvh8_device: the host builder failed on a group the device tree was too deep for";
+                break;
+            }
+            size_t nNodes = 0, nIdx = 0;
+            const void* hNodes = pgpu_host_bvh8_nodes(hb, &nNodes);
+            const uint32_t* hIdx = pgpu_host_bvh8_leaf_indices(hb, &nIdx);
+            std::vector<float> tris((nIdx + 1) * 12, 0.0f);
+            for (size_t sl = 0; sl < nIdx; ++sl) {
+                const uint32_t j = hIdx[sl], prim = group_prims[first + j];
+                for (int k = 0; k < 3; ++k)
+                    std::memcpy(&tris[sl * 12 + size_t(k) * 4], positions + 3u * size_t(indices[3u * size_t(prim) + size_t(k)]), 12);
+                std::memcpy(&tris[sl * 12 + 3], &j, 4);
+            }
+            unsigned char* devNodes = nullptr;
+            float* devTris = nullptr;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&devNodes), std::max<size_t>(nNodes * 256, 256));
+            if (e == hipSuccess) {
+                c->owned.push_back(devNodes);
+                e = hipMalloc(reinterpret_cast<void**>(&devTris), tris.size() * sizeof(float));
+            }
+            if (e == hipSuccess) {
+                c->owned.push_back(devTris);
+                if (nNodes)
+                    e = hipMemcpy(devNodes, hNodes, nNodes * 256, hipMemcpyHostToDevice);
+            }
+            if (e == hipSuccess)
+                e = hipMemcpy(devTris, tris.data(), tris.size() * sizeof(float), hipMemcpyHostToDevice);
+            d.nodes = devNodes;
+            d.tris = reinterpret_cast<const unsigned char*>(devTris);
+            d.root = pgpu_host_bvh8_root(hb);
+            d.n_nodes = uint32_t(nNodes);
+            d.depth = uint32_t(pgpu_host_bvh8_depth(hb));
+            pgpu_host_bvh8_free(hb);
+            if (e != hipSuccess) {
+                rc = fail(c, PGPU_ERR_HIP, "pgpu_build_upload_bvh8_device: upload of a host-built group", e);
+                break;
+            }
+        }
+        c->bvhs.push_back(d);
+        bvh_ids[g] = uint32_t(c->bvhs.size() - 1);
+    }
+    if (rc != PGPU_OK) {
+        c->bvhs.resize(firstId); // (the arenas stay with the context until it shuts down)
+        return rc;
+    }
+    c->staged.resize(c->bvhs.size());
+    c->bvhTableDirty = true;
+    if (n_host_built)
+        *n_host_built = hostBuilt;
+    return syncBvhTable(c);
+}
+
+// A resident or staged BVH back in the reference's arrays (what pgpu_upload_bvh8 was given): for trees that were built on the device,
+// checks, and the on-disk format (pgpu_bvh8_serialize).
+extern "C" int pgpu_bvh8_info(pgpu_ctx* c, uint32_t bvh_id, size_t* n_nodes, size_t* n_indices, uint32_t* root_handle, int* depth)
+{
+    if (!c || bvh_id >= c->bvhs.size())
+        return fail(c, PGPU_ERR_INVALID, "pgpu_bvh8_info: unknown bvh id");
+    const Bvh8Dev& d = c->bvhs[bvh_id];
+    if (n_nodes)
+        *n_nodes = d.n_nodes;
+    if (n_indices)
+        *n_indices = d.n_slots;
+    if (root_handle)
+        *root_handle = d.root;
+    if (depth)
+        *depth = int(d.depth);
+    return PGPU_OK;
+}
+
+extern "C" int pgpu_download_bvh8(pgpu_ctx* c, uint32_t bvh_id, void* nodes256, uint32_t* leaf_indices)
+{
+    if (!c || bvh_id >= c->bvhs.size() || !leaf_indices)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_download_bvh8: unknown bvh id or null argument");
+    const Bvh8Dev& d = c->bvhs[bvh_id];
+    if (d.n_nodes && !nodes256)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_download_bvh8: null node array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<float> tris(size_t(d.n_slots) * 12u);
+    if (bvh_id < c->staged.size() && c->staged[bvh_id].host) { // kept in pinned host memory: nodes, then (256-aligned) the records
+        const StagedBvh& st = c->staged[bvh_id];
+        if (d.n_nodes)
+            std::memcpy(nodes256, st.host, size_t(d.n_nodes) * 256u);
+        std::memcpy(tris.data(), st.host + alignUp(st.nodeBytes), tris.size() * sizeof(float));
+    } else {
+        if (!d.nodes || !d.tris)
+            return fail(c, PGPU_ERR_NO_SCENE, "pgpu_download_bvh8: the BVH is not resident on this GPU");
+        HIP_TRY(c, hipDeviceSynchronize());
+        if (d.n_nodes)
+            HIP_TRY(c, hipMemcpy(nodes256, d.nodes, size_t(d.n_nodes) * 256u, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(tris.data(), d.tris, tris.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    for (size_t sl = 0; sl < d.n_slots; ++sl)
+        std::memcpy(&leaf_indices[sl], &tris[sl * 12u + 3u], 4); // (the leaf-object index rides in p0.w of every record)
     return PGPU_OK;
 }

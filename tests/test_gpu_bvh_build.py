@@ -183,3 +183,50 @@ def test_groups_too_deep_for_the_stack_go_to_the_host_builder(ctx, monkeypatch):
         check_tree(hb, mesh, 4)
     host = pa.accel.build_bvh8(mesh.pos, mesh.idx, groups[0])
     assert np.array_equal(host.nodes.view(np.uint32), bvhs[0].nodes.view(np.uint32)) and np.array_equal(host.leaf_idx, bvhs[0].leaf_idx)
+
+
+def test_trees_built_and_left_on_the_device_trace_like_the_same_trees_uploaded(ctx):
+    """pgpu_build_upload_bvh8_device: no host copy of the trees exists until pgpu_download_bvh8 fetches one; what comes back is
+    what pgpu_build_bvh8_device returns for the same groups, and traces through the resident trees equal the oracle's."""
+    mesh = pa.scenes.g_city(4, 6000)
+    c2 = pa.accel.Context(0)
+    try:
+        c2.set_keep_shading(True)
+        tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 4000, svdag_res=16, resident_ctx=c2, svdag_device_ctx=c2)
+        assert tl.bvh_ids is not None and all(b is None for b in tl.bvhs)
+        tl.upload(c2, 0)
+        rays = pa.scenes.random_rays(mesh.pos.min(0), mesh.pos.max(0), 60_000, seed=11)
+        got, cnt = c2.trace(rays)
+        tl.fetch_bvhs(c2)
+        ref, _ = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, tl.groups)
+        for a, b in zip(tl.bvhs, ref):
+            assert np.array_equal(a.nodes.view(np.uint32), b.nodes.view(np.uint32)) and np.array_equal(a.leaf_idx, b.leaf_idx)
+            assert (a.root, a.depth) == (b.root, b.depth)
+        want = ob.scene_from_two_level(tl, mesh).trace(rays)
+        for k in ("t", "obj", "leaf", "u", "v", "visits"):
+            assert np.array_equal(np.asarray(got[k]).view(np.uint32), want[k].view(np.uint32)), k
+        any_got, _ = c2.trace(rays, kind=pa.capi.ANY)
+        assert np.array_equal(np.asarray(any_got["hit"]), ob.scene_from_two_level(tl, mesh).trace(rays, any_hit=True)["hit"])
+    finally:
+        c2.close()
+
+
+def test_single_resident_tree_and_the_host_fallback(ctx, monkeypatch):
+    mesh = pa.scenes.g_small()
+    rays = pa.scenes.primary_rays((0, 1, 3.2), (0, 1, 0), (0, 1, 0), 50, 96, 96)
+    for levels, fell_back in ((None, 0), ("2", 1)):
+        if levels:
+            monkeypatch.setenv("PANDORA_BVH8_DEVICE_LEVELS", levels)
+        c2 = pa.accel.Context(0)
+        try:
+            (bid,), host_built = c2.build_upload_bvh8_device(mesh.pos, mesh.idx)
+            assert host_built == fell_back
+            hb = c2.download_bvh8(bid, np.arange(mesh.n_tris, dtype=np.uint32))
+            check_tree(hb, mesh, 4)
+            got = c2.trace_bvh8(bid, rays)
+            want = ob.OracleBvh8.from_host(hb, mesh).trace(rays)
+            for k in ("t", "obj", "u", "v"):
+                assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+            assert (want["obj"] != ob.MISS).mean() > 0.5
+        finally:
+            c2.close()
