@@ -79,8 +79,8 @@ def parse_args():
     ap.add_argument("--two-level-steps", type=int, default=10, help="timed steps of the `two_level` sub-record")
     ap.add_argument("--top-variant", type=int, default=0, help="two-level: pgpu_set_top_variant (0 automatic, 1 lockstep waves, 2 independent lanes, 3 lockstep first episode then lanes)")
     ap.add_argument("--batch-parts", type=int, default=0, help="two-level: pgpu_set_batch_parts (0 = the library's default: two parts from 2^21 rays on; 1 = the batch as one)")
-    ap.add_argument("--builder", choices=["host", "device"], default="host",
-                    help="bottom-level BVH8 construction: host = binary SAH tree collapsed by dynamic programming (the default, the best trees), device = pgpu_build_bvh8_device (LBVH on the GPU, every batching point in one pass)")
+    ap.add_argument("--builder", choices=["host", "device", "resident"], default="host",
+                    help="bottom-level BVH8 construction: host = binary SAH tree collapsed by dynamic programming (the default, the best trees), device = pgpu_build_bvh8_device (LBVH on the GPU, every batching point in one pass, trees returned to the host and uploaded like the host builder's), resident = pgpu_build_upload_bvh8_device (the same trees, never leaving the GPU)")
     ap.add_argument("--dry", action="store_true", help="no GPU: the ranks only meet (gloo) and reduce made-up figures; checks the launch path")
     return ap.parse_args()
 
@@ -153,10 +153,17 @@ def run_single(args, pa, torch, ctx, dev, rank):
     if args.builder == "device":
         (hb,), _ = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx)
         build_device_ms = ctx.last_kernel_ms()
+    elif args.builder == "resident":
+        (bvh,), _ = ctx.build_upload_bvh8_device(mesh.pos, mesh.idx)
+        build_device_ms = ctx.last_kernel_ms()
     else:
         hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
     build_s = time.perf_counter() - t_build
-    bvh = ctx.upload_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
+    if args.builder == "resident":
+        hb = ctx.download_bvh8(bvh, np.arange(mesh.n_tris, dtype=np.uint32))  # (for the CPU baseline and the hit -> triangle table; not part of the build)
+    else:
+        bvh = ctx.upload_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
+    ready_s = time.perf_counter() - t_build
     stream = torch.cuda.current_stream().cuda_stream
     prim = pa.scenes.primary_rays((3, 3, 9), (28, 5, 9), (0, 1, 0), 70, args.side, args.side, seed=891379 + 7919 * rank)
     d_prim = torch.from_numpy(prim).to(dev)
@@ -221,7 +228,7 @@ def run_single(args, pa, torch, ctx, dev, rank):
                 issue = tj.get("issue")  # what actually bounds the kernel: VALU issue slots used, lanes active, waves waiting (same PMC passes)
         config = {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-%s %s-hit" % (mesh.n_tris, args.rays, args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
-                  "bvh8_builder": args.builder, "bvh8_build_s": build_s, "bvh8_build_device_ms": build_device_ms,
+                  "bvh8_builder": args.builder, "bvh8_build_s": build_s, "bvh8_build_device_ms": build_device_ms, "bvh8_built_and_uploaded_s": ready_s,
                   "triangle_test": args.tri, "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src, "issue": issue, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
@@ -233,12 +240,12 @@ def run_single(args, pa, torch, ctx, dev, rank):
     return step, n, finish
 
 
-def city_scene(pa, blocks, build_group=None, svdag=64, ctx=None, bvh_on_device=False):
+def city_scene(pa, blocks, build_group=None, svdag=64, ctx=None, builder="host"):
     """ctx: build the SVDAGs on that context's GPU (pgpu_build_svdags_device: 33 ms instead of 0.9 s for this scene);
-    bvh_on_device: the batching points' BVH8s too (pgpu_build_bvh8_device)."""
+    builder: "device" / "resident" = the batching points' BVH8s too (pgpu_build_bvh8_device / pgpu_build_upload_bvh8_device)."""
     mesh = pa.scenes.g_city(blocks, 18750)
     tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 65536, svdag_res=svdag, build_group=build_group, svdag_device_ctx=ctx,
-                                  bvh_device_ctx=ctx if bvh_on_device else None)
+                                  bvh_device_ctx=ctx if builder == "device" else None, resident_ctx=ctx if builder == "resident" else None)
     return mesh, tl
 
 
@@ -250,9 +257,10 @@ def city_camera(pa, blocks, side, seed):
 def run_two_level(args, pa, torch, ctx, dev, rank):
     """configs[2]: PauseableBVH4 + 64^3 SVDAGs + per-point BVH8 on one GPU (the whole round loop is the step)."""
     t_build = time.perf_counter()
-    mesh, tl = city_scene(pa, args.city_blocks, svdag=args.svdag, ctx=ctx, bvh_on_device=(args.builder == "device"))
+    mesh, tl = city_scene(pa, args.city_blocks, svdag=args.svdag, ctx=ctx, builder=args.builder)
     build_s = time.perf_counter() - t_build
-    tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+    tl.upload(ctx, 0 if args.builder == "resident" else ctx.upload_mesh(mesh.pos, mesh.idx))
+    ready_s = time.perf_counter() - t_build
     if args.svdag_defer:
         ctx.set_svdag_defer(args.svdag_defer, 2)
     ctx.set_svdag_policy(1 if args.svdag_policy == "nonresident" else 0)
@@ -276,6 +284,8 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
 
     def finish(k_ms, world):
         cnt = state["cnt"]
+        if tl.bvh_ids is not None:  # trees that never left the GPU: the figures below and the CPU baseline want them on the host
+            tl.fetch_bvhs(ctx)
         scene_bytes = tl.device_bytes(mesh.n_verts)
         per_ray = 52 if args.kind == "closest" else 36
         # per (ray, batching-point visit) a park + a resume record of 44 bytes each (ray 32 + token 12)
@@ -300,7 +310,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
                    "gpu_matches_bit_exact": bool(same)}
         config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with %d^3 SVDAG early-out%s + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.svdag, "" if args.svdag_policy == "always" else " for non-resident points only (here: none)", args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "batching_points": tl.n_leaves, "triangle_test": args.tri,
-                  "bvh8_builder": args.builder, "scene_build_s": build_s,
+                  "bvh8_builder": args.builder, "scene_build_s": build_s, "scene_built_and_uploaded_s": ready_s,
                   "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         # memory-side bytes per step from rocprofv3 PMC passes of this same command (tools/pmc_two_level_traffic.py), quoted as for
