@@ -66,9 +66,11 @@ void pgpu_host_bvh8_free(pgpu_host_bvh8*);
  * Morton order per group, one binary radix tree over all groups, boxes bottom-up, collapse into 8-wide nodes, the reference's
  * 256-byte nodes and octant words written by the device. Group g = triangles group_prims[group_offsets[g] .. group_offsets[g+1])
  * of the mesh (host arrays; offsets start at 0 and increase); out[g] receives the same kind of object pgpu_build_bvh8 returns
- * (leaf object j of a group = its j-th triangle) and is freed with pgpu_host_bvh8_free. Trees are of LBVH quality (about a fifth
- * more node visits per ray than pgpu_build_bvh8's) and built some hundred times faster. A group whose device tree would nest
- * deeper than 12 inner nodes is built by pgpu_build_bvh8 instead; *n_host_built (may be NULL) says how many were.
+ * (leaf object j of a group = its j-th triangle) and is freed with pgpu_host_bvh8_free. Trees are of LBVH quality (on the
+ * benchmark atrium 14 % more node visits per diffuse ray than pgpu_build_bvh8's, 10 % fewer rays per second) and cost 9 ms of GPU
+ * time for 11.4 M triangles in 256 groups (the host builder: 0.4 s on 16 threads). Node numbering is breadth first per group and does
+ * not depend on the run or on the other groups of the call. A group whose device tree would nest deeper than 12 inner nodes is
+ * built by pgpu_build_bvh8 instead; *n_host_built (may be NULL) says how many were.
  * pgpu_last_kernel_ms = device time of the build. max_leaf in 1..4, at most 2^20 groups and 2^31 - 2 triangles in all. */
 int pgpu_build_bvh8_device(pgpu_ctx*, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
     const uint32_t* group_prims, const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, pgpu_host_bvh8** out,
