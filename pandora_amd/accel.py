@@ -785,7 +785,7 @@ class TwoLevelScene:
         return len(self.groups)
 
     def fetch_bvhs(self, ctx: "Context"):
-        """Trees that were built on the device (build_two_level(..., resident_ctx=ctx)) brought back as HostBvh8s, for the oracle
+        """Trees that were built on the device (build_two_level(..., resident_ctx=ctx)) brought back as HostBvh8s, for checks
         and the on-disk format."""
         self.bvhs = [ctx.download_bvh8(int(i), g) if int(i) != capi.NO_BVH else None for i, g in zip(self.bvh_ids, self.groups)]
         return self
