@@ -81,6 +81,7 @@ def parse_args():
     ap.add_argument("--batch-parts", type=int, default=0, help="two-level: pgpu_set_batch_parts (0 = the library's default: two parts from 2^21 rays on; 1 = the batch as one)")
     ap.add_argument("--builder", choices=["host", "device", "resident"], default="host",
                     help="bottom-level BVH8 construction: host = binary SAH tree collapsed by dynamic programming (the default, the best trees), device = pgpu_build_bvh8_device (LBVH on the GPU, every batching point in one pass, trees returned to the host and uploaded like the host builder's), resident = pgpu_build_upload_bvh8_device (the same trees, never leaving the GPU)")
+    ap.add_argument("--cut", choices=["host", "device"], default="host", help="two-level: the cut into batching points: host = binned-SAH BVH2 cut (pgpu_partition_prims, the default), device = the same rule on an LBVH built on the GPU (pgpu_partition_prims_device)")
     ap.add_argument("--dry", action="store_true", help="no GPU: the ranks only meet (gloo) and reduce made-up figures; checks the launch path")
     return ap.parse_args()
 
@@ -240,12 +241,13 @@ def run_single(args, pa, torch, ctx, dev, rank):
     return step, n, finish
 
 
-def city_scene(pa, blocks, build_group=None, svdag=64, ctx=None, builder="host"):
+def city_scene(pa, blocks, build_group=None, svdag=64, ctx=None, builder="host", cut="host"):
     """ctx: build the SVDAGs on that context's GPU (pgpu_build_svdags_device: 33 ms instead of 0.9 s for this scene);
     builder: "device" / "resident" = the batching points' BVH8s too (pgpu_build_bvh8_device / pgpu_build_upload_bvh8_device)."""
     mesh = pa.scenes.g_city(blocks, 18750)
     tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 65536, svdag_res=svdag, build_group=build_group, svdag_device_ctx=ctx,
-                                  bvh_device_ctx=ctx if builder == "device" else None, resident_ctx=ctx if builder == "resident" else None)
+                                  bvh_device_ctx=ctx if builder == "device" else None, resident_ctx=ctx if builder == "resident" else None,
+                                  cut_ctx=ctx if cut == "device" else None)
     return mesh, tl
 
 
@@ -257,7 +259,7 @@ def city_camera(pa, blocks, side, seed):
 def run_two_level(args, pa, torch, ctx, dev, rank):
     """configs[2]: PauseableBVH4 + 64^3 SVDAGs + per-point BVH8 on one GPU (the whole round loop is the step)."""
     t_build = time.perf_counter()
-    mesh, tl = city_scene(pa, args.city_blocks, svdag=args.svdag, ctx=ctx, builder=args.builder)
+    mesh, tl = city_scene(pa, args.city_blocks, svdag=args.svdag, ctx=ctx, builder=args.builder, cut=args.cut)
     build_s = time.perf_counter() - t_build
     tl.upload(ctx, 0 if args.builder == "resident" else ctx.upload_mesh(mesh.pos, mesh.idx))
     ready_s = time.perf_counter() - t_build
@@ -310,7 +312,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
                    "gpu_matches_bit_exact": bool(same)}
         config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with %d^3 SVDAG early-out%s + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.svdag, "" if args.svdag_policy == "always" else " for non-resident points only (here: none)", args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "batching_points": tl.n_leaves, "triangle_test": args.tri,
-                  "bvh8_builder": args.builder, "scene_build_s": build_s, "scene_built_and_uploaded_s": ready_s,
+                  "bvh8_builder": args.builder, "cut": args.cut, "scene_build_s": build_s, "scene_built_and_uploaded_s": ready_s,
                   "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         # memory-side bytes per step from rocprofv3 PMC passes of this same command (tools/pmc_two_level_traffic.py), quoted as for

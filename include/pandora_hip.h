@@ -86,6 +86,11 @@ int pgpu_build_upload_bvh8_device(pgpu_ctx*, const float* positions, size_t n_ve
  * bytes) and leaf_indices (n_indices words). For trees built on the device, for checks, and for pgpu_bvh8_serialize. */
 int pgpu_bvh8_info(pgpu_ctx*, uint32_t bvh_id, size_t* n_nodes, size_t* n_indices, uint32_t* root_handle, int* depth);
 int pgpu_download_bvh8(pgpu_ctx*, uint32_t bvh_id, void* nodes256, uint32_t* leaf_indices);
+/* pgpu_partition_prims (below) on the GPU of `ctx`: the mesh in Morton order, a binary radix tree over it, and the subtrees of at most
+ * max_prims triangles under a parent that holds more -- the cut of detail::createSubScenes (batching.cpp:38-265) on an LBVH. Groups are
+ * numbered along the Morton curve; pgpu_last_kernel_ms = device time. */
+int pgpu_partition_prims_device(pgpu_ctx*, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    size_t max_prims, uint32_t* group_of_prim, uint32_t* n_groups);
 /* BVH8 over arbitrary leaf objects given by their bounds (n_objects x {min xyz, max xyz}); leaf object j = box j. An object
  * with alone[j] != 0 gets a leaf of its own (instances; alone may be NULL). What LRUBVHSceneCache::createBVH builds over
  * the mix of instanced sub-scenes and triangles of a sub-scene (offline_bvh_cache.cpp:273-309). */

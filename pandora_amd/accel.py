@@ -312,6 +312,16 @@ def partition_prims(pos: np.ndarray, idx: np.ndarray, max_prims: int):
     return out, int(ng.value)
 
 
+def partition_prims_device(ctx: "Context", pos: np.ndarray, idx: np.ndarray, max_prims: int):
+    """partition_prims on the GPU of `ctx` (pgpu_partition_prims_device: the cut on an LBVH). -> (group_of_prim uint32[nt], n_groups)."""
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    out = np.empty(idx.shape[0], np.uint32)
+    ng = C.c_uint32()
+    _check(capi.lib().pgpu_partition_prims_device(ctx._h, pos.ctypes.data, pos.shape[0], idx.ctypes.data, idx.shape[0], max_prims, out.ctypes.data, C.byref(ng)), ctx._h)
+    return out, int(ng.value)
+
+
 @dataclass
 class HostSvdags:
     words: np.ndarray       # shared uint32 node array
@@ -854,17 +864,18 @@ class TwoLevelScene:
 
 
 def build_two_level(pos, idx, prims_per_batching_point: int, svdag_res: int = 0, max_leaf: int = 4, build_group=None,
-                    svdag_device_ctx: "Context | None" = None, bvh_device_ctx: "Context | None" = None, resident_ctx: "Context | None" = None) -> TwoLevelScene:
+                    svdag_device_ctx: "Context | None" = None, bvh_device_ctx: "Context | None" = None, resident_ctx: "Context | None" = None, cut_ctx: "Context | None" = None) -> TwoLevelScene:
     """build_group: optional callable (group sizes: int array[, top: HostBvh4]) -> bool array; only those batching points get a
     bottom-level BVH8 here (the others stay None: they live on another rank). A callable that takes two arguments also gets the
     top level, which is built first (from the groups' bounds) so that ownership can follow its leaf order. The cut, the top
     level and the SVDAGs are always whole. svdag_device_ctx: build the SVDAGs on that context's GPU instead of the host;
     bvh_device_ctx: likewise the bottom-level BVH8s (LBVH quality, see pgpu_build_bvh8_device); resident_ctx: the BVH8s are built on
     that context's GPU and stay there (pgpu_build_upload_bvh8_device: `bvh_ids` instead of `bvhs`; upload() then only adds the
-    SVDAGs and the top level, fetch_bvhs() brings the trees back when the host wants them)."""
+    SVDAGs and the top level, fetch_bvhs() brings the trees back when the host wants them); cut_ctx: the cut into batching points on
+    that context's GPU as well (pgpu_partition_prims_device)."""
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
-    group_of, ng = partition_prims(pos, idx, prims_per_batching_point)
+    group_of, ng = partition_prims(pos, idx, prims_per_batching_point) if cut_ctx is None else partition_prims_device(cut_ctx, pos, idx, prims_per_batching_point)
     order = np.argsort(group_of, kind="stable").astype(np.uint32)
     counts = np.bincount(group_of, minlength=ng)
     starts = np.concatenate([[0], np.cumsum(counts)])

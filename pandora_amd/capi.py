@@ -159,6 +159,7 @@ SYMBOLS = {
                                          C.POINTER(C.c_uint32)]),
     "pgpu_build_upload_bvh8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                                 C.POINTER(C.c_uint32)]),
+    "pgpu_partition_prims_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint32)]),
     "pgpu_bvh8_info": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "pgpu_download_bvh8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pgpu_set_round_lookahead": (C.c_int, [C.c_void_p, C.c_int]),

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) primBoundsKernel(const float* __restrict_
                 hi = mid;
         }
         g = lo;
-        const uint32_t t = prims[p];
+        const uint32_t t = prims ? prims[p] : p; // (no list: the mesh's triangles in their order)
         Box6 b;
         for (int a = 0; a < 3; ++a) {
             const float v0 = pos[3u * size_t(idx[3u * size_t(t)]) + a], v1 = pos[3u * size_t(idx[3u * size_t(t) + 1u]) + a],
@@ -459,6 +459,35 @@ __global__ void __launch_bounds__(256) emitKernel(uint32_t n, const uint32_t* __
         nd[48 + j] = __uint_as_float(r.handle[j]);
         nd[56 + j] = __uint_as_float(perm[j]);
     }
+}
+
+// ---- the scene cut on the same radix tree (pgpu_partition_prims_device): with the whole mesh as one group, the subtrees that hold
+// at most maxPrims triangles under a parent that holds more are the batching points. Sorted positions are cut into runs; a run's
+// number is the count of run starts up to it.
+__global__ void __launch_bounds__(256) cutKernel(uint32_t n, uint32_t maxPrims, const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi,
+    const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf, uint32_t* __restrict__ startFlag)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n)
+        return;
+    auto count = [&](uint32_t node) { return rangeHi[node] - rangeLo[node] + 1u; };
+    // as a triangle: a run of its own when its parent is too large to be one (n == 1: no parent)
+    const uint32_t pl = parentLeaf[i];
+    if (pl == kNone || count(pl) > maxPrims)
+        startFlag[i] = 1u;
+    // as an internal node (i < n - 1)
+    if (i + 1u < n && count(i) <= maxPrims) {
+        const uint32_t pi = parentInt[i];
+        if (pi == kNone || count(pi) > maxPrims)
+            startFlag[rangeLo[i]] = 1u;
+    }
+}
+
+__global__ void __launch_bounds__(256) groupOfKernel(uint32_t n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ startScan, uint32_t* __restrict__ groupOfPrim)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p < n)
+        groupOfPrim[order[p]] = startScan[p] - 1u; // (inclusive scan of the run starts)
 }
 
 // ---- 7. (pgpu_build_upload_bvh8_device) the 48-byte triangle records of the trees, slot by slot: what pgpu_upload_bvh8 gathers on
@@ -953,5 +982,95 @@ extern "C" int pgpu_download_bvh8(pgpu_ctx* c, uint32_t bvh_id, void* nodes256, 
     }
     for (size_t sl = 0; sl < d.n_slots; ++sl)
         std::memcpy(&leaf_indices[sl], &tris[sl * 12u + 3u], 4); // (the leaf-object index rides in p0.w of every record)
+    return PGPU_OK;
+}
+
+// The cut of a mesh into batching points (pgpu_partition_prims; the reference: detail::createSubScenes, batching.cpp:38-265) on the
+// GPU: Morton order of the whole mesh (21 bits per axis), the radix tree, and the subtrees of at most max_prims triangles under a
+// parent that holds more. Groups are numbered along the Morton curve. LBVH quality: the groups are boxes of the Morton grid rather
+// than a SAH cut's, and some are small (a subtree next to a large sibling).
+extern "C" int pgpu_partition_prims_device(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles,
+    size_t max_prims, uint32_t* group_of_prim, uint32_t* n_groups)
+{
+    const TraceRange range_("pgpu_partition_prims_device");
+    if (!c || !positions || !indices || !group_of_prim || !n_groups || max_prims == 0 || n_triangles == 0)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_partition_prims_device: null or empty argument");
+    if (n_vertices > 0xFFFFFFFFull / 3 || n_triangles >= 0x7FFFFFFFull / 3)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_partition_prims_device: more than 2^31 / 3 triangles or 2^32 / 3 vertices");
+    for (size_t i = 0; i < 3 * n_triangles; ++i)
+        if (indices[i] >= n_vertices)
+            return fail(c, PGPU_ERR_INVALID, "pgpu_partition_prims_device: vertex index out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = c->stream;
+    Scratch mem;
+    const uint32_t N = uint32_t(n_triangles);
+    const uint32_t maxPrims = uint32_t(std::min<size_t>(max_prims, 0xFFFFFFFFu));
+    float* dPos = nullptr;
+    uint32_t *dIdx = nullptr, *dGroupOf = nullptr, *dCBounds = nullptr, *dVals = nullptr, *dOrder = nullptr, *dLeft = nullptr, *dRight = nullptr, *dLo = nullptr, *dHi = nullptr,
+             *dParentInt = nullptr, *dParentLeaf = nullptr, *dGroupRoot = nullptr, *dFlag = nullptr, *dScan = nullptr, *dOut = nullptr;
+    unsigned long long *dOffsets = nullptr, *dKeys = nullptr, *dKeysSorted = nullptr;
+    Box6* dPrimBox = nullptr;
+    HIP_TRY(c, mem.alloc(&dPos, 3 * n_vertices));
+    HIP_TRY(c, mem.alloc(&dIdx, 3 * n_triangles));
+    HIP_TRY(c, mem.alloc(&dOffsets, 2));
+    HIP_TRY(c, mem.alloc(&dGroupOf, N));
+    HIP_TRY(c, mem.alloc(&dCBounds, 6));
+    HIP_TRY(c, mem.alloc(&dPrimBox, N));
+    HIP_TRY(c, mem.alloc(&dKeys, N));
+    HIP_TRY(c, mem.alloc(&dKeysSorted, N));
+    HIP_TRY(c, mem.alloc(&dVals, N));
+    HIP_TRY(c, mem.alloc(&dOrder, N));
+    HIP_TRY(c, mem.alloc(&dLeft, N));
+    HIP_TRY(c, mem.alloc(&dRight, N));
+    HIP_TRY(c, mem.alloc(&dLo, N));
+    HIP_TRY(c, mem.alloc(&dHi, N));
+    HIP_TRY(c, mem.alloc(&dParentInt, N));
+    HIP_TRY(c, mem.alloc(&dParentLeaf, N));
+    HIP_TRY(c, mem.alloc(&dGroupRoot, 1));
+    HIP_TRY(c, mem.alloc(&dFlag, N));
+    HIP_TRY(c, mem.alloc(&dScan, N));
+    HIP_TRY(c, mem.alloc(&dOut, N));
+    const int bitsPerAxis = 21;
+    size_t sortBytes = 0, scanBytes = 0;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, dKeys, dKeysSorted, dVals, dOrder, int(N), 0, 3 * bitsPerAxis, stream));
+    HIP_TRY(c, hipcub::DeviceScan::InclusiveSum(nullptr, scanBytes, dFlag, dScan, int(N), stream));
+    unsigned char* dTemp = nullptr;
+    HIP_TRY(c, mem.alloc(&dTemp, std::max(sortBytes, scanBytes)));
+    const unsigned long long offsets[2] = { 0ull, N };
+    const uint32_t boundsInit[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u };
+    HIP_TRY(c, hipMemcpyAsync(dPos, positions, 3 * n_vertices * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(dIdx, indices, 3 * n_triangles * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(dOffsets, offsets, sizeof(offsets), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(dCBounds, boundsInit, sizeof(boundsInit), hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream)); // (the two small arrays live on this frame)
+    HIP_TRY(c, hipMemsetAsync(dParentInt, 0xFF, size_t(N) * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(dParentLeaf, 0xFF, size_t(N) * 4, stream));
+    HIP_TRY(c, hipMemsetAsync(dFlag, 0, size_t(N) * 4, stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, stream));
+    hipLaunchKernelGGL(primBoundsKernel, dim3(blocksFor(N)), dim3(256), 0, stream, dPos, dIdx, static_cast<const uint32_t*>(nullptr), dOffsets, 1u, N, dGroupOf, dPrimBox, dCBounds);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(mortonKernel, dim3(blocksFor(N)), dim3(256), 0, stream, dPrimBox, dGroupOf, dCBounds, N, bitsPerAxis, dKeys, dVals);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dTemp, sortBytes, dKeys, dKeysSorted, dVals, dOrder, int(N), 0, 3 * bitsPerAxis, stream));
+    if (N > 1u) {
+        hipLaunchKernelGGL(hierarchyKernel, dim3(blocksFor(N - 1u)), dim3(256), 0, stream, dKeysSorted, N, dGroupOf, dOffsets, dLeft, dRight, dLo, dHi, dParentInt, dParentLeaf,
+            dGroupRoot);
+        HIP_TRY(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(cutKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, maxPrims, dLo, dHi, dParentInt, dParentLeaf, dFlag);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipcub::DeviceScan::InclusiveSum(dTemp, scanBytes, dFlag, dScan, int(N), stream));
+    hipLaunchKernelGGL(groupOfKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dScan, dOut);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, stream));
+    uint32_t groups = 0;
+    HIP_TRY(c, hipMemcpyAsync(group_of_prim, dOut, size_t(N) * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipMemcpyAsync(&groups, dScan + (N - 1u), 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    HIP_TRY(c, hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->ev1));
+    c->timingStale = false;
+    if (groups == 0 || groups > N)
+        return fail(c, PGPU_ERR_HIP, "pgpu_partition_prims_device: the cut is not a partition (internal error)");
+    *n_groups = groups;
     return PGPU_OK;
 }

@@ -230,3 +230,38 @@ def test_single_resident_tree_and_the_host_fallback(ctx, monkeypatch):
             assert (want["obj"] != ob.MISS).mean() > 0.5
         finally:
             c2.close()
+
+
+def test_the_cut_on_the_device_is_a_partition_within_the_budget_and_traces_like_any_other(ctx):
+    mesh = pa.scenes.g_city(4, 6000)
+    for budget in (4000, 300, 1, 10**9):
+        group_of, ng = pa.accel.partition_prims_device(ctx, mesh.pos, mesh.idx, budget)
+        counts = np.bincount(group_of, minlength=ng)
+        assert group_of.size == mesh.n_tris and counts.min() >= 1 and counts.max() <= budget and counts.sum() == mesh.n_tris
+        assert ng == (1 if budget >= mesh.n_tris else ng) and (budget != 1 or ng == mesh.n_tris)
+        again, ng2 = pa.accel.partition_prims_device(ctx, mesh.pos, mesh.idx, budget)
+        assert ng2 == ng and np.array_equal(again, group_of)
+    group_of, ng = pa.accel.partition_prims_device(ctx, mesh.pos, mesh.idx, 4000)
+    host_ng = pa.accel.partition_prims(mesh.pos, mesh.idx, 4000)[1]
+    assert ng < 3 * host_ng  # (an LBVH cut leaves small groups next to large siblings; it must not shatter the scene)
+    # groups are spatially compact: the sum of the groups' box surfaces stays within a small factor of the host cut's
+    def surface(gof, n):
+        tri = mesh.pos[mesh.idx]
+        order = np.argsort(gof, kind="stable")
+        at = np.concatenate([[0], np.cumsum(np.bincount(gof, minlength=n))])[:-1]
+        lo = np.minimum.reduceat(tri.min(axis=1)[order], at, axis=0)
+        hi = np.maximum.reduceat(tri.max(axis=1)[order], at, axis=0)
+        d = hi - lo
+        return float((d[:, 0] * d[:, 1] + d[:, 1] * d[:, 2] + d[:, 2] * d[:, 0]).sum())
+    assert surface(group_of, ng) < 3.0 * surface(*pa.accel.partition_prims(mesh.pos, mesh.idx, 4000))
+    c2 = pa.accel.Context(0)
+    try:
+        tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 4000, svdag_res=16, cut_ctx=c2, resident_ctx=c2, svdag_device_ctx=c2)
+        tl.upload(c2, 0)
+        rays = pa.scenes.random_rays(mesh.pos.min(0), mesh.pos.max(0), 40_000, seed=13)
+        got, _ = c2.trace(rays)
+        want = ob.scene_from_two_level(tl.fetch_bvhs(c2), mesh).trace(rays)
+        for k in ("t", "obj", "leaf", "u", "v", "visits"):
+            assert np.array_equal(np.asarray(got[k]).view(np.uint32), want[k].view(np.uint32)), k
+    finally:
+        c2.close()
