@@ -322,7 +322,18 @@ static int multi()
     AdapterOptions directStreamed = streamed; // ... and streamed points keep their test: everything as in the reference
     directStreamed.svdagOnlyForNonResident = true;
     const bool okDS = same(runScene(shapes, directStreamed, n, 4), "one context, streamed, SVDAG test for non-resident points only");
-    if (!okS || !okS2 || !refused || !okD || !okDS)
+    // the batching points' BVH8s built on the GPU: other trees, the same scene -- same batching points, same visits at the top
+    // level, the same hits but for rays that meet two triangles a last bit apart (which one a traversal keeps depends on the tree)
+    AdapterOptions onDevice = one;
+    onDevice.buildOnDevice = true;
+    const Outcome dv = runScene(shapes, onDevice, n, 4);
+    size_t differ = 0;
+    for (int i = 0; i < n; ++i)
+        differ += dv.shape[size_t(i)] != a.shape[size_t(i)] || dv.prim[size_t(i)] != a.prim[size_t(i)] || dv.tBits[size_t(i)] != a.tBits[size_t(i)]
+            || dv.shadow[size_t(i)] != a.shadow[size_t(i)];
+    const bool okDv = dv.traced == a.traced && differ <= size_t(n) / 2000 && dv.counters.svdag_tests == a.counters.svdag_tests;
+    std::printf("one context, BVH8s built on the device: %s (%zu of %d rays differ, traced %zu)\n", okDv ? "same scene" : "DIFFERENT", differ, n, dv.traced);
+    if (!okS || !okS2 || !refused || !okD || !okDS || !okDv)
         return 1;
     if (hits < size_t(n) / 2 || shadowed == 0 || shadowed == hits || !okB || !okC || !okR || c.counters.records_routed == 0)
         return 1;
