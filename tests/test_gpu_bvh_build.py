@@ -265,3 +265,73 @@ def test_the_cut_on_the_device_is_a_partition_within_the_budget_and_traces_like_
             assert np.array_equal(np.asarray(got[k]).view(np.uint32), want[k].view(np.uint32)), k
     finally:
         c2.close()
+
+
+def _walk_only(hb):
+    """Handles in range, every slot once (no geometry involved: for meshes whose bounds are not numbers)."""
+    nu = hb.nodes.view(np.uint32)
+    seen, slots, depth = set(), [], 0
+    stack = [(hb.root, 0)]
+    while stack:
+        h, d = stack.pop()
+        flags, i = h >> 29, h & 0x1FFFFFFF
+        if flags == 2:
+            assert i < hb.n_nodes and i not in seen
+            seen.add(i)
+            depth = max(depth, d + 1)
+            stack.extend((int(c), d + 1) for c in nu[i, 48:56] if c != 0)
+        else:
+            assert flags & 4
+            slots.extend(range(i, i + (flags & 3) + 1))
+    assert len(seen) == hb.n_nodes and sorted(slots) == list(range(hb.leaf_idx.size)) and depth == hb.depth <= 12
+    assert sorted(hb.leaf_idx.tolist()) == list(range(hb.prim_ids.size))
+
+
+@pytest.mark.parametrize("max_leaf", [1, 4])
+def test_hostile_meshes_through_the_device_builder(ctx, max_leaf):
+    """The meshes and rays of tests/test_gpu_fuzz.py (zero-area, collinear, flat, huge, duplicated, tiny triangles; rays with zero /
+    infinite / NaN components and inverted intervals) through device-built trees, returned and resident: valid trees, traces equal
+    to the oracle's on the same tree bit for bit. Then vertices that are not numbers: the build must stay a tree and the trace must
+    come back (what such triangles hit is nobody's contract)."""
+    from test_gpu_fuzz import _bits, _nasty_mesh, _nasty_rays
+    rng = np.random.default_rng(300 + max_leaf)
+    pos, idx = _nasty_mesh(rng, 1600)
+    mesh = pa.scenes.Mesh(pos, idx)
+    third = idx.shape[0] // 3
+    groups = [np.arange(0, third, dtype=np.uint32), np.arange(third, idx.shape[0], dtype=np.uint32)]
+    bvhs, host_built = pa.accel.build_bvh8_device(ctx, pos, idx, groups, max_leaf=max_leaf)
+    assert host_built == 0
+    rays = _nasty_rays(rng, 30000)
+    c2 = pa.accel.Context(0)
+    try:
+        ids, _ = c2.build_upload_bvh8_device(pos, idx, groups, max_leaf=max_leaf)
+        with np.errstate(all="ignore"):
+            for hb, bid, g in zip(bvhs, ids, groups):
+                check_tree(hb, mesh, max_leaf)
+                back = c2.download_bvh8(int(bid), g)
+                assert np.array_equal(back.nodes.view(np.uint32), hb.nodes.view(np.uint32)) and np.array_equal(back.leaf_idx, hb.leaf_idx)
+                orc = ob.OracleBvh8.from_host(hb, mesh)
+                for tri in (pa.capi.TRI_MT, pa.capi.TRI_WATERTIGHT):
+                    want = orc.trace(rays, tri_mode=tri, threads=8)
+                    got = c2.trace_bvh8(int(bid), rays, tri_mode=tri)
+                    for k in ("t", "obj", "u", "v"):
+                        assert np.array_equal(_bits(got[k]), _bits(want[k])), (tri, k)
+                    assert np.array_equal(c2.trace_bvh8(int(bid), rays, kind=pa.capi.ANY, tri_mode=tri)["hit"], orc.trace(rays, any_hit=True, tri_mode=tri, threads=8)["hit"])
+        bad = pos.copy()
+        sel = rng.random(bad.shape[0])
+        bad[sel < 0.02] = np.nan
+        bad[(sel >= 0.02) & (sel < 0.04), 1] = np.inf
+        bad[(sel >= 0.04) & (sel < 0.05)] = -np.inf
+        bad[(sel >= 0.05) & (sel < 0.06)] = np.float32(3e38)
+        worse, _ = pa.accel.build_bvh8_device(ctx, bad, idx, groups, max_leaf=max_leaf)
+        for hb in worse:
+            _walk_only(hb)
+        ids2, _ = c2.build_upload_bvh8_device(bad, idx, groups, max_leaf=max_leaf)
+        for bid in ids2:
+            out = c2.trace_bvh8(int(bid), rays)
+            assert out["t"].shape[0] == rays.shape[1]
+        all_nan = np.full_like(pos, np.nan)
+        for hb in pa.accel.build_bvh8_device(ctx, all_nan, idx, groups, max_leaf=max_leaf)[0]:
+            _walk_only(hb)
+    finally:
+        c2.close()
