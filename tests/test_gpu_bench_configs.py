@@ -59,3 +59,18 @@ def test_default_line_carries_the_two_level_record_small():
     assert "error" not in t and t["gpu_matches_bit_exact"] is True and t["value"] > 0 and t["ms_per_step"] > 0
     assert "configs[2]" in t["config"]["workload"] and t["roofline"]["frac"] > 0 and t["cpu_baseline"]["value"] > 0
     assert "sharded" not in j
+
+
+@pytest.mark.timeout(450)
+@pytest.mark.parametrize("extra", [("--builder", "device"), ("--builder", "resident"), ("--builder", "resident", "--cut", "device")], ids=["device", "resident", "resident_device_cut"])
+def test_two_level_config_with_trees_built_on_the_gpu_small(extra):
+    j = _bench("--config", "two-level", "--city-blocks", "4", "--side", "512", "--svdag", "32", *extra)
+    assert j["cpu_baseline"]["gpu_matches_bit_exact"] is True
+    assert j["config"]["bvh8_builder"] == extra[1] and j["config"]["batching_points"] >= 2 and j["value"] > 0
+
+
+@pytest.mark.timeout(450)
+@pytest.mark.parametrize("builder", ["device", "resident"])
+def test_single_level_config_with_a_tree_built_on_the_gpu_small(builder):
+    j = _bench("--tris", "20000", "--side", "512", "--no-two-level", "--builder", builder)
+    assert j["cpu_baseline"]["gpu_matches_bit_exact"] is True and j["config"]["bvh8_builder"] == builder and j["config"]["bvh8_build_device_ms"] > 0
