@@ -63,11 +63,11 @@ int pgpu_host_bvh8_depth(const pgpu_host_bvh8*); /* nested inner nodes on the lo
 void pgpu_host_bvh8_free(pgpu_host_bvh8*);
 /* The BVH8s of many triangle groups (batching points) at once, built on the GPU of `ctx` (pandora_amd/csrc/bvh_build.hip; the
  * reference builds one tree per batching point with Embree on the CPU, wive_bvh8_build8_impl.h:87-104, offline_bvh_cache.cpp:273-309):
- * Morton order per group, one binary radix tree over all groups, boxes bottom-up, collapse into 8-wide nodes, the reference's
- * 256-byte nodes and octant words written by the device. Group g = triangles group_prims[group_offsets[g] .. group_offsets[g+1])
+ * Morton order per group, one binary radix tree over all groups, boxes and the collapse's cost tables bottom-up, collapse into 8-wide
+ * nodes by those tables, the reference's 256-byte nodes and octant words written by the device. Group g = triangles group_prims[group_offsets[g] .. group_offsets[g+1])
  * of the mesh (host arrays; offsets start at 0 and increase); out[g] receives the same kind of object pgpu_build_bvh8 returns
  * (leaf object j of a group = its j-th triangle) and is freed with pgpu_host_bvh8_free. Trees are of LBVH quality (on the
- * benchmark atrium 14 % more node visits per diffuse ray than pgpu_build_bvh8's, 10 % fewer rays per second) and cost 9 ms of GPU
+ * benchmark atrium 10 % more node visits per diffuse ray than pgpu_build_bvh8's, 7 % fewer rays per second) and cost 11 ms of GPU
  * time for 11.4 M triangles in 256 groups (the host builder: 0.4 s on 16 threads). Node numbering is breadth first per group and does
  * not depend on the run or on the other groups of the call. A group whose device tree would nest deeper than 12 inner nodes is
  * built by pgpu_build_bvh8 instead; *n_host_built (may be NULL) says how many were.

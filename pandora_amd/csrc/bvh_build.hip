@@ -11,11 +11,13 @@
 //   3. one binary radix tree over the whole sorted array (Karras 2012: every internal node finds its range and split with two
 //      binary searches over common prefix lengths; equal keys fall back to the index) -- the group id is the top of the key, so
 //      every group's triangles are exactly one subtree; its root is the node whose range is the group's;
-//   4. boxes bottom-up (the second thread to arrive at a node computes it);
-//   5. collapse into 8-wide nodes, level by level from all group roots at once: a node adopts the children of the child with
-//      the largest surface until it has eight (subtrees of at most max_leaf triangles are leaves on sight, as in the host's
-//      greedy construction); children too large for what is left of the depth budget are opened first, largest first. Node indices are handed
-//      out per group, so every handle is local to its group's node array from the start;
+//   4. boxes bottom-up (the second thread to arrive at a node computes it), and with them the cost tables of the collapse: per node
+//      the cheapest forest of at most 1..8 wide-tree roots below it (the host builder's dynamic programme, run on the radix tree);
+//   5. collapse into 8-wide nodes, level by level from all group roots at once: a node takes the roots its tables name. A group
+//      whose tree comes out deeper than the traversal stack allows goes through a second pass in which a node adopts the children
+//      of the child with the largest surface until it has eight (subtrees of at most max_leaf triangles are leaves on sight, as in
+//      the host's greedy construction) and children too large for what is left of the depth budget are opened first, largest
+//      first. Node indices are handed out per group, so every handle is local to its group's node array from the start;
 //   6. emit: the reference's 256-byte nodes (wive_bvh8.h:76-86) with the octant permutation words of
 //      wive_bvh8_build8_impl.h:172-203, group after group in one array, and the leaf-index arrays (= the sorted order).
 // A group whose tree would nest deeper than the traversal stack allows (12 inner nodes, wive_bvh8_impl.h:74-75) is rebuilt by the
@@ -234,9 +236,20 @@ __device__ __forceinline__ void storeNodeBoxCoherent(Box6* p, const Box6& b)
     }
 }
 
+// The same pass carries the tables of the collapse of step 5 (pandora_amd/host/bvh_builder.cpp `solve`, after Ylitie, Karras and Laine
+// 2017): per node cost[j], j = 1..8, the cheapest forest of at most j wide-tree roots that covers the subtree -- one root is a leaf
+// (at most maxLeaf triangles) or a wide node, each at its surface; more roots are the best split of j between the two children --
+// and, packed in one word, where the j roots are cut (3 bits per j = 2..8), how a wide node here divides its eight slots
+// (bits 21..23) and whether the one-root form is a node (bit 24).
+__device__ __forceinline__ float halfArea(const Box6& b)
+{
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
 __global__ void __launch_bounds__(256) fitKernel(uint32_t n, const uint32_t* __restrict__ order, const Box6* __restrict__ primBox, const uint32_t* __restrict__ left,
     const uint32_t* __restrict__ right, const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf, uint32_t* __restrict__ visits,
-    Box6* nodeBox)
+    Box6* nodeBox, const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi, uint32_t maxLeaf, float* cost, uint32_t* cutWord)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n)
@@ -256,6 +269,46 @@ __global__ void __launch_bounds__(256) fitKernel(uint32_t n, const uint32_t* __r
             u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
         }
         storeNodeBoxCoherent(nodeBox + cur, u);
+        if (cost) {
+            float cl[9], cr[9]; // [1..8]
+            for (int j = 1; j <= 8; ++j) {
+                cl[j] = (l & kLeafRef) ? halfArea(a) : __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(cost) + size_t(l) * 8u + (j - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                cr[j] = (r & kLeafRef) ? halfArea(b) : __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(cost) + size_t(r) * 8u + (j - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            const float area = halfArea(u);
+            const uint32_t cnt = rangeHi[cur] - rangeLo[cur] + 1u;
+            const float asLeaf = cnt <= maxLeaf ? area : __builtin_inff();
+            float bestKids = cl[1] + cr[7];
+            uint32_t kLeft = 1;
+            for (uint32_t k = 2; k <= 7u; ++k) {
+                const float v = cl[k] + cr[8u - k];
+                if (v < bestKids) {
+                    bestKids = v;
+                    kLeft = k;
+                }
+            }
+            const float asInner = area + bestKids;
+            const bool inner1 = cnt > maxLeaf || asInner < asLeaf; // (more than a leaf holds: a node whatever the numbers say)
+            float cj[9];
+            cj[1] = inner1 ? asInner : asLeaf;
+            uint32_t word = (kLeft << 21) | (inner1 ? 1u << 24 : 0u);
+            for (uint32_t j = 2; j <= 8u; ++j) {
+                float best = cj[1];
+                uint32_t cut = 0;
+                for (uint32_t k = 1; k < j; ++k) {
+                    const float v = cl[k] + cr[j - k];
+                    if (v < best) {
+                        best = v;
+                        cut = k;
+                    }
+                }
+                cj[j] = best;
+                word |= cut << ((j - 2u) * 3u);
+            }
+            for (int j = 1; j <= 8; ++j)
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(cost) + size_t(cur) * 8u + (j - 1), __float_as_uint(cj[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cutWord[cur] = word; // (read by later kernels only)
+        }
         cur = parentInt[cur];
     }
 }
@@ -273,7 +326,7 @@ __device__ __forceinline__ uint32_t handleLeaf(uint32_t i, uint32_t n) { return 
 __global__ void __launch_bounds__(256) expandKernel(const WorkItem* __restrict__ in, uint32_t nIn, uint32_t level, uint32_t maxLevels, uint32_t maxLeaf, unsigned long long capacity,
     const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi,
     const Box6* __restrict__ nodeBox, const unsigned long long* __restrict__ offsets, NodeRec* __restrict__ recs, uint32_t* __restrict__ innerCount,
-    uint32_t* __restrict__ groupDepth, uint32_t* __restrict__ groupFailed)
+    uint32_t* __restrict__ groupDepth, uint32_t* __restrict__ groupFailed, const uint32_t* __restrict__ cutWord)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k > nIn)
@@ -289,7 +342,33 @@ __global__ void __launch_bounds__(256) expandKernel(const WorkItem* __restrict__
     kids[1] = right[w.node];
     for (int j = 2; j < 8; ++j)
         kids[j] = kNone;
-    while (n < 8) {
+    if (cutWord) {
+        // the roots the tables of fitKernel name: the node's eight slots divided between its two subtrees, each share cut further
+        // wherever more roots are cheaper than one
+        uint32_t todoNode[8], todoRoots[8];
+        int top = 0;
+        n = 0;
+        const uint32_t kLeft = (cutWord[w.node] >> 21) & 7u;
+        todoNode[top] = kids[1];
+        todoRoots[top++] = 8u - kLeft;
+        todoNode[top] = kids[0];
+        todoRoots[top++] = kLeft;
+        while (top > 0 && n < 8) {
+            const uint32_t i = todoNode[--top], j = todoRoots[top];
+            const uint32_t cut = ((i & kLeafRef) || j < 2u) ? 0u : (cutWord[i] >> ((j - 2u) * 3u)) & 7u;
+            if (cut == 0u || cut >= j || top + 2 > 8) {
+                kids[n++] = i;
+            } else {
+                todoNode[top] = right[i];
+                todoRoots[top++] = j - cut;
+                todoNode[top] = left[i];
+                todoRoots[top++] = cut;
+            }
+        }
+        for (int j = n; j < 8; ++j)
+            kids[j] = kNone;
+    }
+    while (!cutWord && n < 8) {
         // open the child the depth budget cannot hold, else the one with the largest surface; subtrees of <= maxLeaf triangles are leaves
         int pick = -1;
         float best = -1.0f;
@@ -343,7 +422,8 @@ __global__ void __launch_bounds__(256) expandKernel(const WorkItem* __restrict__
             r.handle[j] = handleLeaf((ref & ~kLeafRef) - base, 1u);
         } else {
             const uint32_t cnt = rangeHi[ref] - rangeLo[ref] + 1u;
-            if (cnt <= maxLeaf)
+            const bool asLeaf = cutWord ? ((cutWord[ref] >> 24) & 1u) == 0u && cnt <= maxLeaf : cnt <= maxLeaf;
+            if (asLeaf)
                 r.handle[j] = handleLeaf(rangeLo[ref] - base, cnt);
             else
                 ++nInner;
@@ -611,6 +691,14 @@ int buildOnDevice(pgpu_ctx* c, const float* positions, size_t n_vertices, const 
     HIP_TRY(c, mem.alloc(&dParentLeaf, N));
     HIP_TRY(c, mem.alloc(&dVisits, N));
     HIP_TRY(c, mem.alloc(&dNodeBox, N));
+    float* dCost = nullptr;
+    uint32_t* dCutWord = nullptr;
+    const char* collapseEnv = std::getenv("PANDORA_BVH8_DEVICE_COLLAPSE"); // "greedy": without the tables (A/B, tests)
+    const bool tables = !(collapseEnv && std::strcmp(collapseEnv, "greedy") == 0);
+    if (tables) {
+        HIP_TRY(c, mem.alloc(&dCost, size_t(N) * 8u));
+        HIP_TRY(c, mem.alloc(&dCutWord, N));
+    }
     HIP_TRY(c, mem.alloc(&dGroupRoot, n_groups));
     HIP_TRY(c, mem.alloc(&dGroupNodes, n_groups));
     HIP_TRY(c, mem.alloc(&dGroupDepth, n_groups));
@@ -660,7 +748,8 @@ int buildOnDevice(pgpu_ctx* c, const float* positions, size_t n_vertices, const 
         hipLaunchKernelGGL(hierarchyKernel, dim3(blocksFor(N - 1u)), dim3(256), 0, stream, dKeysSorted, N, dGroupOf, dOffsets, dLeft, dRight, dLo, dHi, dParentInt,
             dParentLeaf, dGroupRoot);
         HIP_TRY(c, hipGetLastError());
-        hipLaunchKernelGGL(fitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dPrimBox, dLeft, dRight, dParentInt, dParentLeaf, dVisits, dNodeBox);
+        hipLaunchKernelGGL(fitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dPrimBox, dLeft, dRight, dParentInt, dParentLeaf, dVisits, dNodeBox, dLo, dHi,
+            max_leaf, dCost, dCutWord);
         HIP_TRY(c, hipGetLastError());
     }
     // seeds, in group order: the root of every group that is more than one leaf
@@ -686,30 +775,67 @@ int buildOnDevice(pgpu_ctx* c, const float* positions, size_t n_vertices, const 
     int margin = 2;
     if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_MARGIN"))
         margin = std::max(0, std::min(kMaxLevels, std::atoi(e)));
-    uint32_t count = uint32_t(seeds.size());
-    for (int level = 0; level < maxLevels && count != 0u; ++level) {
-        if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG"))
-            std::fprintf(stderr, "bvh_build: level %d, %u nodes\n", level, count);
-        // A child of a node at this level may root (maxLevels - 1 - level) levels of inner nodes, which hold max_leaf * 8^that
-        // triangles if every node below is full. A radix tree is not that regular: children are opened by size rather than by
-        // surface once they hold what `margin` levels fewer could (a sparse scene's largest boxes are single triangles near the
-        // root; opening by surface alone peels them off one level at a time and runs out of depth on the dense parts).
-        unsigned long long capacity = max_leaf;
-        for (int l = level + 1 + margin; l < maxLevels; ++l)
-            capacity *= 8ull;
-        hipLaunchKernelGGL(expandKernel, dim3(blocksFor(size_t(count) + 1)), dim3(256), 0, stream, dQueue[level & 1], count, uint32_t(level), uint32_t(maxLevels), max_leaf,
-            capacity, dLeft, dRight, dLo, dHi, dNodeBox, dOffsets, dRecs, dInnerCount, dGroupDepth, dGroupFailed);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dScanTemp, scanBytes, dInnerCount, dSlotStart, int(count) + 1, stream));
-        hipLaunchKernelGGL(assignKernel, dim3(blocksFor(count)), dim3(256), 0, stream, dQueue[level & 1], count, dInnerCount, dSlotStart, dOffsets, dRecs,
-            dQueue[(level + 1) & 1], dGroupNodes);
-        HIP_TRY(c, hipGetLastError());
-        uint32_t next = 0;
-        HIP_TRY(c, hipMemcpyAsync(&next, dSlotStart + count, 4, hipMemcpyDeviceToHost, stream));
+    // The collapse runs level by level over whatever queue it is given. First pass: every group, by the tables. The tables know
+    // nothing of the depth budget; a group whose tree comes out deeper than the traversal stack allows goes through a second pass
+    // that opens children by surface and, near the budget, by size (what then still does not fit is the host builder's).
+    auto collapse = [&](uint32_t count, bool useTables) -> int {
+        for (int level = 0; level < maxLevels && count != 0u; ++level) {
+            if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG"))
+                std::fprintf(stderr, "bvh_build: level %d, %u nodes\n", level, count);
+            // A child of a node at this level may root (maxLevels - 1 - level) levels of inner nodes, which hold max_leaf * 8^that
+            // triangles if every node below is full. A radix tree is not that regular: children are opened by size rather than by
+            // surface once they hold what `margin` levels fewer could (a sparse scene's largest boxes are single triangles near the
+            // root; opening by surface alone peels them off one level at a time and runs out of depth on the dense parts).
+            unsigned long long capacity = max_leaf;
+            for (int l = level + 1 + margin; l < maxLevels; ++l)
+                capacity *= 8ull;
+            hipLaunchKernelGGL(expandKernel, dim3(blocksFor(size_t(count) + 1)), dim3(256), 0, stream, dQueue[level & 1], count, uint32_t(level), uint32_t(maxLevels), max_leaf,
+                capacity, dLeft, dRight, dLo, dHi, dNodeBox, dOffsets, dRecs, dInnerCount, dGroupDepth, dGroupFailed, useTables ? dCutWord : nullptr);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dScanTemp, scanBytes, dInnerCount, dSlotStart, int(count) + 1, stream));
+            hipLaunchKernelGGL(assignKernel, dim3(blocksFor(count)), dim3(256), 0, stream, dQueue[level & 1], count, dInnerCount, dSlotStart, dOffsets, dRecs,
+                dQueue[(level + 1) & 1], dGroupNodes);
+            HIP_TRY(c, hipGetLastError());
+            uint32_t next = 0;
+            HIP_TRY(c, hipMemcpyAsync(&next, dSlotStart + count, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipStreamSynchronize(stream));
+            if (next >= N)
+                return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: work queue overran (internal error)");
+            count = next;
+        }
+        return PGPU_OK;
+    };
+    {
+        const int rcA = collapse(uint32_t(seeds.size()), tables);
+        if (rcA != PGPU_OK)
+            return rcA;
+    }
+    if (tables) {
+        std::vector<uint32_t> failedA(n_groups), zeros(n_groups, 0u);
+        HIP_TRY(c, hipMemcpyAsync(failedA.data(), dGroupFailed, n_groups * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c, hipMemcpyAsync(nodeCount.data(), dGroupNodes, n_groups * 4, hipMemcpyDeviceToHost, stream));
+        std::vector<uint32_t> depthA(n_groups);
+        HIP_TRY(c, hipMemcpyAsync(depthA.data(), dGroupDepth, n_groups * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(c, hipStreamSynchronize(stream));
-        if (next >= N)
-            return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: work queue overran (internal error)");
-        count = next;
+        std::vector<WorkItem> again;
+        for (const WorkItem& w : seeds)
+            if (failedA[w.group]) {
+                again.push_back(w);
+                nodeCount[w.group] = 1u;
+                depthA[w.group] = 0u;
+            }
+        if (!again.empty()) {
+            if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG"))
+                std::fprintf(stderr, "bvh_build: %zu groups too deep by the tables, second pass\n", again.size());
+            HIP_TRY(c, hipMemcpyAsync(dGroupNodes, nodeCount.data(), n_groups * 4, hipMemcpyHostToDevice, stream));
+            HIP_TRY(c, hipMemcpyAsync(dGroupDepth, depthA.data(), n_groups * 4, hipMemcpyHostToDevice, stream));
+            HIP_TRY(c, hipMemsetAsync(dGroupFailed, 0, n_groups * 4, stream));
+            HIP_TRY(c, hipMemcpyAsync(dQueue[0], again.data(), again.size() * sizeof(WorkItem), hipMemcpyHostToDevice, stream));
+            HIP_TRY(c, hipStreamSynchronize(stream)); // (`again` and the vectors above go out of scope)
+            const int rcB = collapse(uint32_t(again.size()), false);
+            if (rcB != PGPU_OK)
+                return rcB;
+        }
     }
     std::vector<uint32_t>&depth = b.depth, &failed = b.failed, &nodeBase = b.nodeBase;
     depth.assign(n_groups, 0u);

@@ -335,3 +335,25 @@ def test_hostile_meshes_through_the_device_builder(ctx, max_leaf):
             _walk_only(hb)
     finally:
         c2.close()
+
+
+def test_both_collapses_give_valid_trees_and_the_tables_give_the_smaller_one(ctx, monkeypatch):
+    """The collapse by cost tables (default) against the one that opens children by surface (PANDORA_BVH8_DEVICE_COLLAPSE=greedy; also
+    the second pass for groups the tables make too deep -- forced here with a budget of 5 levels)."""
+    mesh = pa.scenes.g_atrium(30_000)
+    (by_tables,), _ = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx)
+    monkeypatch.setenv("PANDORA_BVH8_DEVICE_COLLAPSE", "greedy")
+    (greedy,), _ = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx)
+    monkeypatch.delenv("PANDORA_BVH8_DEVICE_COLLAPSE")
+    check_tree(by_tables, mesh, 4)
+    check_tree(greedy, mesh, 4)
+    assert by_tables.n_nodes < 0.9 * greedy.n_nodes
+    rays = pa.scenes.random_rays(mesh.pos.min(0), mesh.pos.max(0), 20_000, seed=3)
+    a = ob.OracleBvh8.from_host(by_tables, mesh).trace(rays)
+    b = ob.OracleBvh8.from_host(greedy, mesh).trace(rays)
+    assert np.count_nonzero(a["t"].view(np.uint32) != b["t"].view(np.uint32)) <= 2e-4 * rays.shape[1]
+    assert a["counters"]["inner_visits"] < b["counters"]["inner_visits"] and a["counters"]["tri_tests"] < b["counters"]["tri_tests"]
+    monkeypatch.setenv("PANDORA_BVH8_DEVICE_LEVELS", str(max(1, by_tables.depth - 1)))  # the tables' tree no longer fits: second pass (or the host)
+    (second,), host_built = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx)
+    check_tree(second, mesh, 4)
+    assert second.depth <= by_tables.depth - 1 or host_built == 1
