@@ -9,10 +9,15 @@ import pandora_amd as pa
 import oracle_binding as ob
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+builder = sys.argv[2] if len(sys.argv) > 2 else "host"  # "resident": the tree built on the GPU and left there (pgpu_build_upload_bvh8_device)
 mesh = pa.scenes.g_atrium(262144)
-hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
 ctx = pa.accel.Context(0)
-bvh = ctx.upload_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
+if builder == "resident":
+    (bvh,), _ = ctx.build_upload_bvh8_device(mesh.pos, mesh.idx)
+    hb = ctx.download_bvh8(bvh, np.arange(mesh.n_tris, dtype=np.uint32))
+else:
+    hb = pa.accel.build_bvh8(mesh.pos, mesh.idx)
+    bvh = ctx.upload_bvh8(hb, ctx.upload_mesh(mesh.pos, mesh.idx))
 orc = ob.OracleBvh8.from_host(hb, mesh)
 prim = pa.scenes.primary_rays((3, 3, 9), (28, 5, 9), (0, 1, 0), 70, side, side)
 w = ctx.trace_bvh8(bvh, prim)
@@ -20,7 +25,7 @@ obj = w["obj"].view(np.uint32)
 primid = np.where(obj == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), hb.prim_ids[np.minimum(obj, hb.prim_ids.size - 1)])
 diff = pa.scenes.diffuse_bounce_rays(mesh, prim, w["t"], primid)
 threads = max(1, min(16, os.cpu_count() or 1))
-report = {"rays": {"primary": int(prim.shape[1]), "diffuse": int(diff.shape[1])}, "triangles": int(mesh.n_tris), "cases": []}
+report = {"rays": {"primary": int(prim.shape[1]), "diffuse": int(diff.shape[1])}, "triangles": int(mesh.n_tris), "builder": builder, "bvh8_nodes": hb.n_nodes, "cases": []}
 for name, rays in (("primary", prim), ("diffuse", diff)):
     d = torch.from_numpy(rays).cuda()
     for tri, tri_name in ((pa.capi.TRI_MT, "moller-trumbore"), (pa.capi.TRI_WATERTIGHT, "watertight")):
