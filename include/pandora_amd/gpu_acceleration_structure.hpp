@@ -89,7 +89,9 @@ struct AdapterOptions {
     bool svdagOnlyForNonResident = false;
     // The batching points' BVH8s built by the first device's GPU, all in one pass (pgpu_build_bvh8_device), instead of one
     // pgpu_build_bvh8 per point on the host's threads: the scene is ready sooner, a ray pays a few per cent more.
-    // The trees come back to the host, so staging and the other devices' uploads work as with the host builder's.
+    // With every batching point resident on every device (no cache budget, not LeafSharded) each device builds its own copy and
+    // keeps it (pgpu_build_upload_bvh8_device: the trees never exist on the host; the build is deterministic, so the copies are
+    // the same); otherwise the trees come back to the host, and staging and the owners' uploads work as with the host builder's.
     bool buildOnDevice = false;
 };
 
@@ -1018,6 +1020,9 @@ public:
         } freeBuilt { built };
         std::vector<std::vector<pgpu_leafobj>> objs(nGroups);
         std::vector<float> bounds(6 * size_t(nGroups));
+        // (LeafSharded needs two batching points at least, like everything two-level: decided below, the same way)
+        const bool residentBuild = m_options.buildOnDevice && m_options.botLevelBVHCacheBytes == 0 && !(nGroups >= 2 && m_options.multiGpu == MultiGpu::LeafSharded);
+        std::vector<std::vector<uint32_t>> residentIds;
         if (m_options.buildOnDevice) {
             std::vector<uint32_t> flat;
             std::vector<uint64_t> offs { 0 };
@@ -1026,7 +1031,14 @@ public:
                 flat.insert(flat.end(), g.begin(), g.end());
                 offs.push_back(flat.size());
             }
-            check(pgpu_build_bvh8_device(ctx0, pos.data(), nv, idx.data(), nt, flat.data(), offs.data(), nGroups, 4, built.data(), nullptr), ctx0, "pgpu_build_bvh8_device");
+            if (residentBuild) {
+                residentIds.assign(nDev, std::vector<uint32_t>(nGroups, PGPU_NO_BVH));
+                for (size_t d = 0; d < nDev; ++d)
+                    check(pgpu_build_upload_bvh8_device(m.devices[d].ctx, pos.data(), nv, idx.data(), nt, flat.data(), offs.data(), nGroups, 4, residentIds[d].data(), nullptr),
+                        m.devices[d].ctx, "pgpu_build_upload_bvh8_device");
+            } else {
+                check(pgpu_build_bvh8_device(ctx0, pos.data(), nv, idx.data(), nt, flat.data(), offs.data(), nGroups, 4, built.data(), nullptr), ctx0, "pgpu_build_bvh8_device");
+            }
         }
         detail::WorkerPool::wait(m.pool->submit(nGroups, [&](size_t g) {
             if (!m_options.buildOnDevice && pgpu_build_bvh8(pos.data(), nv, idx.data(), nt, groups[g].data(), groups[g].size(), 4, &built[g]) != PGPU_OK)
@@ -1069,6 +1081,10 @@ public:
         std::vector<std::vector<uint32_t>> bvhIds(nDev, std::vector<uint32_t>(nGroups, PGPU_NO_BVH));
         for (size_t d = 0; d < nDev; ++d)
             for (uint32_t g = 0; g < nGroups; ++g) {
+                if (residentBuild) {
+                    bvhIds[d][g] = residentIds[d][g];
+                    continue;
+                }
                 if (m.sharded && ownerOfGroup[g] != d)
                     continue;
                 size_t nNodes = 0, nIdx = 0;

@@ -333,7 +333,20 @@ static int multi()
             || dv.shadow[size_t(i)] != a.shadow[size_t(i)];
     const bool okDv = dv.traced == a.traced && differ <= size_t(n) / 2000 && dv.counters.svdag_tests == a.counters.svdag_tests;
     std::printf("one context, BVH8s built on the device: %s (%zu of %d rays differ, traced %zu)\n", okDv ? "same scene" : "DIFFERENT", differ, n, dv.traced);
-    if (!okS || !okS2 || !refused || !okD || !okDS || !okDv)
+    // the device-built trees are the same wherever they end up: built and kept by each of two contexts, or returned to the host
+    // and streamed through a cache, or sharded over two contexts -- identical to the single context that built and kept them
+    auto sameAsDv = [&](const Outcome& x, const char* name) {
+        const bool ok = x.shape == dv.shape && x.prim == dv.prim && x.tBits == dv.tBits && x.visits == dv.visits && x.shadow == dv.shadow && x.nz == dv.nz
+            && x.traced == dv.traced && x.counters.svdag_tests == dv.counters.svdag_tests && x.counters.leaf_visits == dv.counters.leaf_visits;
+        std::printf("%s: %s\n", name, ok ? "identical" : "DIFFERENT");
+        return ok;
+    };
+    AdapterOptions onDeviceTwo = two, onDeviceStreamed = streamed, onDeviceSharded = sharded;
+    onDeviceTwo.buildOnDevice = onDeviceStreamed.buildOnDevice = onDeviceSharded.buildOnDevice = true;
+    const bool okDv2 = sameAsDv(runScene(shapes, onDeviceTwo, n, 4), "two contexts, each building and keeping its copy of the trees");
+    const bool okDv3 = sameAsDv(runScene(shapes, onDeviceStreamed, n, 4), "device-built trees returned to the host and streamed through a 1 MiB cache");
+    const bool okDv4 = sameAsDv(runScene(shapes, onDeviceSharded, n, 4), "device-built trees returned to the host and sharded over two contexts");
+    if (!okS || !okS2 || !refused || !okD || !okDS || !okDv || !okDv2 || !okDv3 || !okDv4)
         return 1;
     if (hits < size_t(n) / 2 || shadowed == 0 || shadowed == hits || !okB || !okC || !okR || c.counters.records_routed == 0)
         return 1;
