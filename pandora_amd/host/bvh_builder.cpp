@@ -336,6 +336,8 @@ struct Bvh8Builder {
                 }
             }
         }
+        if (bestAxis < 0) // (no split has a cost that compares: boxes that are not numbers -- a balanced split, as for coincident centroids)
+            return splitPart(items, begin, end, true);
         if (bestAxis != 2)
             std::sort(items.begin() + begin, items.begin() + end,
                 [bestAxis](const Item& x, const Item& y) { return x.c[bestAxis] < y.c[bestAxis] || (x.c[bestAxis] == y.c[bestAxis] && x.id < y.id); });
