@@ -14,6 +14,9 @@ MISS = 0xFFFFFFFF
 
 @pytest.fixture(scope="module")
 def ctx():
+    import torch  # (first: torch brings its own HIP runtime, and whichever library loads one first decides for the process)
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
     c = pa.accel.Context(0)
     yield c
     c.close()
