@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 #include <cmath>
@@ -306,6 +307,8 @@ struct Bvh8Builder {
     };
     std::vector<Bin> bins;
     float costInner = 1.0f, costLeaf = 1.0f, costObject = 0.0f;
+    int reinsertPasses = 10;
+    float reinsertFraction = 0.01f;
 
     // exact SAH over the three axes for small ranges (sorted sweep), binned above that
     size_t splitBinary(size_t begin, size_t end, bool forceMedian)
@@ -359,6 +362,189 @@ struct Bvh8Builder {
             bins[size_t(self)].right = r;
         }
         return self;
+    }
+
+    // ---- the binary tree restructured before the collapse: subtrees taken out and put back where they add the least surface area
+    // (Bittner, Hapala, Havran 2013, "Fast insertion-based optimization of bounding volume hierarchies"). Per pass the inner
+    // nodes that look worst (area x area / smallest child x area / mean child) lose their place: the node N and its parent P are
+    // freed, N's sibling moves up, and N's two subtrees are reinserted, the larger first, each under one of the freed nodes at the
+    // position a branch-and-bound search finds. The tree keeps its node count and every object stays one leaf; afterwards the
+    // nodes are renumbered parent first and the objects reordered so that every subtree is a range again (what solve and the
+    // emission expect).
+    struct Link {
+        int parent, left, right;
+    };
+
+    static float unionArea(const Box& a, const Box& b)
+    {
+        Box u = a;
+        u.grow(b);
+        return u.halfArea();
+    }
+
+    void refit(std::vector<Link>& links, int i)
+    {
+        for (; i >= 0; i = links[size_t(i)].parent) {
+            Box u = bins[size_t(links[size_t(i)].left)].box;
+            u.grow(bins[size_t(links[size_t(i)].right)].box);
+            Box& was = bins[size_t(i)].box;
+            if (std::memcmp(&was, &u, sizeof(Box)) == 0)
+                break;
+            was = u;
+        }
+    }
+
+    void optimiseBinary(int passes, float fraction)
+    {
+        const size_t n = bins.size();
+        if (n < 64)
+            return;
+        std::vector<Link> links(n);
+        links[0].parent = -1;
+        for (size_t i = 0; i < n; ++i) {
+            links[i].left = bins[i].left;
+            links[i].right = bins[i].right;
+            if (bins[i].left >= 0) {
+                links[size_t(bins[i].left)].parent = int(i);
+                links[size_t(bins[i].right)].parent = int(i);
+            }
+        }
+        int root = 0;
+        const bool debug = std::getenv("PANDORA_BVH8_REINSERT_DEBUG") != nullptr;
+        std::vector<std::pair<float, int>> worst;
+        std::vector<std::pair<float, int>> heap; // (-induced cost, node): std::push_heap keeps the largest = least induced cost on top
+        auto place = [&](int x, int freeNode) {
+            const Box xb = bins[size_t(x)].box;
+            const float xa = xb.halfArea();
+            float best = FLT_MAX;
+            int at = root;
+            heap.clear();
+            heap.push_back({ -0.0f, root });
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const float induced = -heap.back().first;
+                const int y = heap.back().second;
+                heap.pop_back();
+                if (!(induced + xa < best))
+                    break;
+                const float total = induced + unionArea(bins[size_t(y)].box, xb);
+                if (total < best) {
+                    best = total;
+                    at = y;
+                }
+                const float below = total - bins[size_t(y)].box.halfArea();
+                if (links[size_t(y)].left >= 0 && below + xa < best) {
+                    heap.push_back({ -below, links[size_t(y)].left });
+                    std::push_heap(heap.begin(), heap.end());
+                    heap.push_back({ -below, links[size_t(y)].right });
+                    std::push_heap(heap.begin(), heap.end());
+                }
+            }
+            // freeNode takes at's place, with at and x below it
+            const int up = links[size_t(at)].parent;
+            links[size_t(freeNode)] = { up, at, x };
+            if (up < 0)
+                root = freeNode;
+            else if (links[size_t(up)].left == at)
+                links[size_t(up)].left = freeNode;
+            else
+                links[size_t(up)].right = freeNode;
+            links[size_t(at)].parent = freeNode;
+            links[size_t(x)].parent = freeNode;
+            bins[size_t(freeNode)].box = Box(); // (so that the refit below sees a change)
+            refit(links, freeNode);
+        };
+        for (int pass = 0; pass < passes; ++pass) {
+            worst.clear();
+            for (size_t i = 0; i < n; ++i) {
+                const Link& k = links[i];
+                if (k.left < 0 || k.parent < 0 || links[size_t(k.parent)].parent < 0)
+                    continue;
+                const float a = bins[i].box.halfArea();
+                const float al = bins[size_t(k.left)].box.halfArea(), ar = bins[size_t(k.right)].box.halfArea();
+                const float smallest = std::min(al, ar), mean = 0.5f * (al + ar);
+                if (!(a > 0.0f) || !(smallest > 0.0f))
+                    continue;
+                worst.push_back({ a * (a / smallest) * (a / mean), int(i) });
+            }
+            const size_t take = std::min(worst.size(), std::max<size_t>(1, size_t(double(worst.size()) * fraction)));
+            if (take == 0)
+                break;
+            std::partial_sort(worst.begin(), worst.begin() + take, worst.end(),
+                [](const std::pair<float, int>& x, const std::pair<float, int>& y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+            for (size_t w = 0; w < take; ++w) {
+                const int N = worst[w].second;
+                const int P = links[size_t(N)].parent;
+                if (P < 0 || links[size_t(P)].parent < 0) // (an earlier reinsertion of this pass moved it next to the root)
+                    continue;
+                const int G = links[size_t(P)].parent;
+                const int S = links[size_t(P)].left == N ? links[size_t(P)].right : links[size_t(P)].left;
+                int L = links[size_t(N)].left, R = links[size_t(N)].right;
+                if (links[size_t(G)].left == P)
+                    links[size_t(G)].left = S;
+                else
+                    links[size_t(G)].right = S;
+                links[size_t(S)].parent = G;
+                refit(links, G);
+                if (bins[size_t(L)].box.halfArea() < bins[size_t(R)].box.halfArea())
+                    std::swap(L, R);
+                place(L, N);
+                place(R, P);
+            }
+            if (debug && (pass % 10 == 9 || pass + 1 == passes)) {
+                double sum = 0.0;
+                for (size_t i = 0; i < n; ++i)
+                    if (links[i].left >= 0)
+                        sum += bins[i].box.halfArea();
+                std::fprintf(stderr, "reinsertion pass %d: inner area / root area = %.3f\n", pass + 1, sum / bins[size_t(root)].box.halfArea());
+            }
+        }
+        // renumber parent first, reorder the objects by the new tree's leaf order
+        std::vector<Bin> out;
+        out.reserve(n);
+        std::vector<Item> ordered;
+        ordered.reserve(items.size());
+        const size_t base = bins[0].begin;
+        for (size_t i = 0; i < base; ++i)
+            ordered.push_back(items[i]);
+        std::vector<int> newIndex(n, -1);
+        struct Todo {
+            int node, stage;
+        };
+        std::vector<Todo> stack;
+        stack.push_back({ root, 0 });
+        while (!stack.empty()) {
+            Todo& t = stack.back();
+            const Link& k = links[size_t(t.node)];
+            if (t.stage == 0) {
+                newIndex[size_t(t.node)] = int(out.size());
+                out.emplace_back();
+                Bin& b = out.back();
+                b.box = bins[size_t(t.node)].box;
+                b.begin = ordered.size();
+                if (k.left < 0) {
+                    ordered.push_back(items[bins[size_t(t.node)].begin]);
+                    b.end = ordered.size();
+                    stack.pop_back();
+                    continue;
+                }
+                t.stage = 1;
+                stack.push_back({ k.left, 0 });
+            } else if (t.stage == 1) {
+                t.stage = 2;
+                stack.push_back({ k.right, 0 });
+            } else {
+                Bin& b = out[size_t(newIndex[size_t(t.node)])];
+                b.left = newIndex[size_t(k.left)];
+                b.right = newIndex[size_t(k.right)];
+                b.end = ordered.size();
+                stack.pop_back();
+            }
+        }
+        for (size_t i = ordered.size(); i < items.size(); ++i)
+            ordered.push_back(items[i]);
+        items.swap(ordered);
+        bins.swap(out);
     }
 
     void solve(int at)
@@ -460,6 +646,8 @@ struct Bvh8Builder {
         bins.clear();
         bins.reserve(2 * whole.count());
         buildBinary(whole.begin, whole.end);
+        if (reinsertPasses > 0)
+            optimiseBinary(reinsertPasses, reinsertFraction);
         solve(0);
         if (int(bins[0].height) > kMaxInnerDepth8) {
             bins.clear();
@@ -494,6 +682,10 @@ struct Bvh8Builder {
             costLeaf = float(std::atof(v));
         if (const char* v = std::getenv("PANDORA_SAH_OBJECT"))
             costObject = float(std::atof(v));
+        if (const char* v = std::getenv("PANDORA_BVH8_REINSERT"))
+            reinsertPasses = std::atoi(v);
+        if (const char* v = std::getenv("PANDORA_BVH8_REINSERT_FRACTION"))
+            reinsertFraction = float(std::atof(v));
         uint32_t root = 0;
         if (!(e && std::strcmp(e, "greedy") == 0) && buildCollapsed(whole, &root))
             return root;
