@@ -13,6 +13,10 @@
 //      every group's triangles are exactly one subtree; its root is the node whose range is the group's;
 //   4. boxes bottom-up (the second thread to arrive at a node computes it), and with them the cost tables of the collapse: per node
 //      the cheapest forest of at most 1..8 wide-tree roots below it (the host builder's dynamic programme, run on the radix tree);
+//   3b. by default, instead of 3 and 4: the binary tree by locally-ordered clustering over the same sorted order (clusters merge with
+//      the neighbour, a few places along the Morton curve, with which they make the smallest box; boxes and tables are made with
+//      the nodes), then the triangles reordered so that every subtree is a range again -- the better tree: a diffuse ray of the
+//      benchmark pays 12.7 steps in it instead of 14.2, at the same build time (PANDORA_BVH8_DEVICE_TREE=lbvh keeps 3 and 4);
 //   5. collapse into 8-wide nodes, level by level from all group roots at once: a node takes the roots its tables name. A group
 //      whose tree comes out deeper than the traversal stack allows goes through a second pass in which a node adopts the children
 //      of the child with the largest surface until it has eight (subtrees of at most max_leaf triangles are leaves on sight, as in
@@ -40,6 +44,7 @@ namespace {
 constexpr uint32_t kLeafRef = 0x80000000u; // a binary-tree reference to a single sorted triangle
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kMaxLevels = 12; // nested inner nodes: 7 * 12 + 8 <= 96 stack entries
+constexpr int kPlocMaxRounds = 1024; // rounds of the clustering (and with them the depth of its binary tree)
 
 struct Box6 {
     float lo[3], hi[3];
@@ -247,6 +252,39 @@ __device__ __forceinline__ float halfArea(const Box6& b)
     return dx * dy + dy * dz + dz * dx;
 }
 
+// the tables of a node from its children's (cl, cr: [1..8]); returns the packed word
+__device__ __forceinline__ uint32_t combineTables(const float* cl, const float* cr, float area, uint32_t cnt, uint32_t maxLeaf, float* cj)
+{
+    const float asLeaf = cnt <= maxLeaf ? area : __builtin_inff();
+    float bestKids = cl[1] + cr[7];
+    uint32_t kLeft = 1;
+    for (uint32_t k = 2; k <= 7u; ++k) {
+        const float v = cl[k] + cr[8u - k];
+        if (v < bestKids) {
+            bestKids = v;
+            kLeft = k;
+        }
+    }
+    const float asInner = area + bestKids;
+    const bool inner1 = cnt > maxLeaf || asInner < asLeaf; // (more than a leaf holds: a node whatever the numbers say)
+    cj[1] = inner1 ? asInner : asLeaf;
+    uint32_t word = (kLeft << 21) | (inner1 ? 1u << 24 : 0u);
+    for (uint32_t j = 2; j <= 8u; ++j) {
+        float best = cj[1];
+        uint32_t cut = 0;
+        for (uint32_t k = 1; k < j; ++k) {
+            const float v = cl[k] + cr[j - k];
+            if (v < best) {
+                best = v;
+                cut = k;
+            }
+        }
+        cj[j] = best;
+        word |= cut << ((j - 2u) * 3u);
+    }
+    return word;
+}
+
 __global__ void __launch_bounds__(256) fitKernel(uint32_t n, const uint32_t* __restrict__ order, const Box6* __restrict__ primBox, const uint32_t* __restrict__ left,
     const uint32_t* __restrict__ right, const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf, uint32_t* __restrict__ visits,
     Box6* nodeBox, const uint32_t* __restrict__ rangeLo, const uint32_t* __restrict__ rangeHi, uint32_t maxLeaf, float* cost, uint32_t* cutWord)
@@ -275,42 +313,225 @@ __global__ void __launch_bounds__(256) fitKernel(uint32_t n, const uint32_t* __r
                 cl[j] = (l & kLeafRef) ? halfArea(a) : __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(cost) + size_t(l) * 8u + (j - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 cr[j] = (r & kLeafRef) ? halfArea(b) : __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(cost) + size_t(r) * 8u + (j - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
-            const float area = halfArea(u);
-            const uint32_t cnt = rangeHi[cur] - rangeLo[cur] + 1u;
-            const float asLeaf = cnt <= maxLeaf ? area : __builtin_inff();
-            float bestKids = cl[1] + cr[7];
-            uint32_t kLeft = 1;
-            for (uint32_t k = 2; k <= 7u; ++k) {
-                const float v = cl[k] + cr[8u - k];
-                if (v < bestKids) {
-                    bestKids = v;
-                    kLeft = k;
-                }
-            }
-            const float asInner = area + bestKids;
-            const bool inner1 = cnt > maxLeaf || asInner < asLeaf; // (more than a leaf holds: a node whatever the numbers say)
             float cj[9];
-            cj[1] = inner1 ? asInner : asLeaf;
-            uint32_t word = (kLeft << 21) | (inner1 ? 1u << 24 : 0u);
-            for (uint32_t j = 2; j <= 8u; ++j) {
-                float best = cj[1];
-                uint32_t cut = 0;
-                for (uint32_t k = 1; k < j; ++k) {
-                    const float v = cl[k] + cr[j - k];
-                    if (v < best) {
-                        best = v;
-                        cut = k;
-                    }
-                }
-                cj[j] = best;
-                word |= cut << ((j - 2u) * 3u);
-            }
+            const uint32_t word = combineTables(cl, cr, halfArea(u), rangeHi[cur] - rangeLo[cur] + 1u, maxLeaf, cj);
             for (int j = 1; j <= 8; ++j)
                 __hip_atomic_store(reinterpret_cast<uint32_t*>(cost) + size_t(cur) * 8u + (j - 1), __float_as_uint(cj[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cutWord[cur] = word; // (read by later kernels only)
         }
         cur = parentInt[cur];
     }
+}
+
+// ---- 3b + 4b. the binary tree by locally-ordered clustering instead of steps 3 and 4 (Meister and Bittner 2018, "Parallel
+// locally-ordered clustering for bounding volume hierarchy construction"): every sorted triangle starts as a cluster; per round
+// each cluster looks `radius` places to either side along the Morton order (inside its group) for the neighbour with which it
+// makes the smallest box, pairs that chose each other merge into a node that takes the lower one's place, and the array is
+// compacted (one scan per round hands out the places and the node numbers, so the tree is the same on every run). Ties go to the
+// pair whose first triangles' positions in the group differ in the lowest bits (symmetric, and a group's tree does not depend on
+// what is built next to it; equal boxes, e.g. coincident triangles, pair up (0,1), (2,3), ... instead of forming a chain). Boxes,
+// triangle counts and the tables of the collapse are known the moment a node is made. The leaves of a subtree are no longer a
+// range of the sorted order, which the collapse and the emission rely on: afterwards every triangle finds its place in the tree's
+// own left-to-right order by walking up (plocPositionKernel), and the order, the ranges and the leaf references are rewritten.
+struct PlocCluster {
+    uint32_t ref;   // a sorted triangle (| kLeafRef) or a node
+    uint32_t group;
+    uint32_t first; // position of its first triangle within the group
+};
+
+__global__ void __launch_bounds__(256) plocInitKernel(uint32_t n, const uint32_t* __restrict__ order, const Box6* __restrict__ primBox, const uint32_t* __restrict__ groupOf,
+    const unsigned long long* __restrict__ offsets, PlocCluster* __restrict__ cl, Box6* __restrict__ cBox)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint32_t g = groupOf[p];
+    cl[p] = PlocCluster { p | kLeafRef, g, p - uint32_t(offsets[g]) };
+    cBox[p] = primBox[order[p]];
+}
+
+__device__ __forceinline__ float unionArea(const Box6& a, const Box6& b)
+{
+    Box6 u;
+    for (int k = 0; k < 3; ++k) {
+        u.lo[k] = fminf(a.lo[k], b.lo[k]);
+        u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+    }
+    const float area = halfArea(u);
+    return area == area ? area : FLT_MAX; // (boxes that are not numbers: any partner will do, the same from both sides)
+}
+
+__global__ void __launch_bounds__(256) plocNearestKernel(uint32_t nActive, int radius, const PlocCluster* __restrict__ cl, const Box6* __restrict__ cBox, uint32_t* __restrict__ nn)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nActive)
+        return;
+    const PlocCluster me = cl[i];
+    const Box6 box = cBox[i];
+    float best = 0.0f;
+    uint32_t bestJ = kNone, bestTie = 0u;
+    for (int d = 1; d <= radius; ++d)
+        for (int s = 0; s < 2; ++s) {
+            const long long j = s ? static_cast<long long>(i) + d : static_cast<long long>(i) - d;
+            if (j < 0 || j >= static_cast<long long>(nActive))
+                continue;
+            const PlocCluster other = cl[j];
+            if (other.group != me.group)
+                continue;
+            const float a = unionArea(box, cBox[j]);
+            const uint32_t tie = me.first ^ other.first;
+            if (bestJ == kNone || a < best || (a == best && tie < bestTie)) {
+                best = a;
+                bestJ = uint32_t(j);
+                bestTie = tie;
+            }
+        }
+    nn[i] = bestJ;
+}
+
+// what becomes of every cluster: bit 0 = it keeps a place in the next round's array, bit 32 = it is the lower one of a pair that
+// merges (one element more than there are clusters, so that the exclusive scan also yields the totals)
+__global__ void __launch_bounds__(256) plocFlagKernel(uint32_t nActive, const uint32_t* __restrict__ nn, unsigned long long* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i > nActive)
+        return;
+    if (i == nActive) {
+        flags[i] = 0ull;
+        return;
+    }
+    const uint32_t j = nn[i];
+    const bool merged = j < nActive && nn[j] == i;
+    flags[i] = (merged && j < i) ? 0ull : (1ull | (merged ? 1ull << 32 : 0ull));
+}
+
+__global__ void __launch_bounds__(256) plocCommitKernel(uint32_t nActive, uint32_t n, uint32_t nodesMade, const uint32_t* __restrict__ nn, const unsigned long long* __restrict__ flags,
+    const unsigned long long* __restrict__ places, const PlocCluster* __restrict__ clIn, const Box6* __restrict__ boxIn, PlocCluster* __restrict__ clOut, Box6* __restrict__ boxOut,
+    uint32_t* __restrict__ left, uint32_t* __restrict__ right, Box6* __restrict__ nodeBox, uint32_t* __restrict__ count, uint32_t* __restrict__ parentInt,
+    uint32_t* __restrict__ parentLeaf, uint32_t maxLeaf, float* __restrict__ cost, uint32_t* __restrict__ cutWord)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nActive)
+        return;
+    const unsigned long long f = flags[i];
+    if ((f & 1ull) == 0ull)
+        return;
+    const uint32_t place = uint32_t(places[i] & 0xFFFFFFFFull);
+    if (place >= nActive)
+        return; // (cannot happen: places count the clusters that stay)
+    PlocCluster me = clIn[i];
+    Box6 box = boxIn[i];
+    if (f >> 32) {
+        const uint32_t j = nn[i];
+        const uint32_t node = nodesMade + uint32_t(places[i] >> 32);
+        if (j >= nActive || node + 1u >= n)
+            return; // (cannot happen: a tree over n triangles in G groups has n - G nodes)
+        const uint32_t l = me.ref, r = clIn[j].ref;
+        const Box6 a = box, b = boxIn[j];
+        for (int k = 0; k < 3; ++k) {
+            box.lo[k] = fminf(a.lo[k], b.lo[k]);
+            box.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+        }
+        left[node] = l;
+        right[node] = r;
+        nodeBox[node] = box;
+        const uint32_t cnt = ((l & kLeafRef) ? 1u : count[l]) + ((r & kLeafRef) ? 1u : count[r]);
+        count[node] = cnt;
+        if (l & kLeafRef)
+            parentLeaf[l & ~kLeafRef] = node;
+        else
+            parentInt[l] = node;
+        if (r & kLeafRef)
+            parentLeaf[r & ~kLeafRef] = node;
+        else
+            parentInt[r] = node;
+        if (cost) {
+            float cl[9], cr[9], cj[9];
+            for (int q = 1; q <= 8; ++q) {
+                cl[q] = (l & kLeafRef) ? halfArea(a) : cost[size_t(l) * 8u + (q - 1)];
+                cr[q] = (r & kLeafRef) ? halfArea(b) : cost[size_t(r) * 8u + (q - 1)];
+            }
+            cutWord[node] = combineTables(cl, cr, halfArea(box), cnt, maxLeaf, cj);
+            for (int q = 1; q <= 8; ++q)
+                cost[size_t(node) * 8u + (q - 1)] = cj[q];
+        }
+        me.ref = node;
+    }
+    clOut[place] = me;
+    boxOut[place] = box;
+}
+
+__global__ void __launch_bounds__(256) plocRootsKernel(uint32_t nActive, uint32_t nGroups, const PlocCluster* __restrict__ cl, uint32_t* __restrict__ groupRoot)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nActive)
+        return;
+    const PlocCluster c = cl[i];
+    if (c.group < nGroups && (c.ref & kLeafRef) == 0u)
+        groupRoot[c.group] = c.ref;
+}
+
+// a triangle's place in the left-to-right order of its group's tree: the triangles of every left sibling on the way up come first
+__global__ void __launch_bounds__(256) plocPositionKernel(uint32_t n, uint32_t maxDepth, const uint32_t* __restrict__ groupOf, const unsigned long long* __restrict__ offsets,
+    const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const uint32_t* __restrict__ parentInt, const uint32_t* __restrict__ parentLeaf,
+    const uint32_t* __restrict__ count, uint32_t* __restrict__ newPos, uint32_t* __restrict__ error)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n)
+        return;
+    uint32_t ref = p | kLeafRef, cur = parentLeaf[p], before = 0u, steps = 0u;
+    while (cur != kNone) {
+        if (cur + 1u >= n || ++steps > maxDepth) {
+            atomicOr(error, 1u);
+            break;
+        }
+        if (right[cur] == ref) {
+            const uint32_t l = left[cur];
+            before += (l & kLeafRef) ? 1u : count[l];
+        }
+        ref = cur;
+        cur = parentInt[cur];
+    }
+    const uint32_t g = groupOf[p];
+    const unsigned long long at = offsets[g] + before;
+    if (at >= offsets[g + 1u]) {
+        atomicOr(error, 2u);
+        newPos[p] = p;
+        return;
+    }
+    newPos[p] = uint32_t(at);
+}
+
+// the ranges of the nodes in the new order and the leaf references renamed (into arrays of their own: the walk below reads the old ones)
+__global__ void __launch_bounds__(256) plocRangesKernel(uint32_t nNodes, uint32_t n, uint32_t maxDepth, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+    const uint32_t* __restrict__ count, const uint32_t* __restrict__ newPos, uint32_t* __restrict__ rangeLo, uint32_t* __restrict__ rangeHi, uint32_t* __restrict__ leftOut,
+    uint32_t* __restrict__ rightOut, uint32_t* __restrict__ error)
+{
+    const uint32_t node = blockIdx.x * 256u + threadIdx.x;
+    if (node >= nNodes)
+        return;
+    const uint32_t l = left[node], r = right[node];
+    uint32_t ref = l;
+    for (uint32_t steps = 0; (ref & kLeafRef) == 0u; ++steps) {
+        if (ref >= nNodes || steps > maxDepth) {
+            atomicOr(error, 4u);
+            ref = kLeafRef;
+            break;
+        }
+        ref = left[ref];
+    }
+    const uint32_t first = (ref & ~kLeafRef) < n ? newPos[ref & ~kLeafRef] : 0u;
+    rangeLo[node] = first;
+    rangeHi[node] = first + count[node] - 1u;
+    leftOut[node] = (l & kLeafRef) ? (((l & ~kLeafRef) < n ? newPos[l & ~kLeafRef] : 0u) | kLeafRef) : l;
+    rightOut[node] = (r & kLeafRef) ? (((r & ~kLeafRef) < n ? newPos[r & ~kLeafRef] : 0u) | kLeafRef) : r;
+}
+
+__global__ void __launch_bounds__(256) plocReorderKernel(uint32_t n, const uint32_t* __restrict__ order, const uint32_t* __restrict__ newPos, uint32_t* __restrict__ orderOut)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p < n && newPos[p] < n)
+        orderOut[newPos[p]] = order[p];
 }
 
 // ---- 5. collapse into 8-wide nodes
@@ -744,7 +965,90 @@ int buildOnDevice(pgpu_ctx* c, const float* positions, size_t n_vertices, const 
     hipLaunchKernelGGL(mortonKernel, dim3(blocksFor(N)), dim3(256), 0, stream, dPrimBox, dGroupOf, dCBounds, N, bitsPerAxis, dKeys, dVals);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(dSortTemp, sortBytes, dKeys, dKeysSorted, dVals, dOrder, int(N), 0, endBit, stream));
-    if (N > 1u) {
+    // the binary tree: locally-ordered clustering (PANDORA_BVH8_DEVICE_TREE=ploc, the default; PANDORA_BVH8_DEVICE_PLOC_RADIUS places to
+    // either side, default 3) or the radix tree over the keys (=lbvh; also what is built if the clustering does not finish in
+    // kPlocMaxRounds rounds, which bounds the depth of its tree)
+    int radius = 3;
+    if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_PLOC_RADIUS"))
+        radius = std::max(1, std::min(64, std::atoi(e)));
+    const char* treeEnv = std::getenv("PANDORA_BVH8_DEVICE_TREE");
+    bool clustered = N > 1u && N > G && !(treeEnv && std::strcmp(treeEnv, "lbvh") == 0);
+    if (clustered) {
+        PlocCluster* dCl[2] = { nullptr, nullptr };
+        Box6* dClBox[2] = { nullptr, nullptr };
+        uint32_t *dNn = nullptr, *dCount = nullptr, *dNewPos = nullptr, *dOrder2 = nullptr, *dLeft2 = nullptr, *dRight2 = nullptr, *dError = nullptr;
+        unsigned long long *dFlags = nullptr, *dPlaces = nullptr;
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(c, mem.alloc(&dCl[k], N));
+            HIP_TRY(c, mem.alloc(&dClBox[k], N));
+        }
+        HIP_TRY(c, mem.alloc(&dNn, N));
+        HIP_TRY(c, mem.alloc(&dCount, N));
+        HIP_TRY(c, mem.alloc(&dNewPos, N));
+        HIP_TRY(c, mem.alloc(&dOrder2, N));
+        HIP_TRY(c, mem.alloc(&dLeft2, N));
+        HIP_TRY(c, mem.alloc(&dRight2, N));
+        HIP_TRY(c, mem.alloc(&dError, 1));
+        HIP_TRY(c, mem.alloc(&dFlags, size_t(N) + 1));
+        HIP_TRY(c, mem.alloc(&dPlaces, size_t(N) + 1));
+        size_t placeBytes = 0;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, placeBytes, dFlags, dPlaces, int(N) + 1, stream));
+        unsigned char* dPlaceTemp = nullptr;
+        HIP_TRY(c, mem.alloc(&dPlaceTemp, placeBytes));
+        HIP_TRY(c, hipMemsetAsync(dError, 0, 4, stream));
+        hipLaunchKernelGGL(plocInitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dPrimBox, dGroupOf, dOffsets, dCl[0], dClBox[0]);
+        HIP_TRY(c, hipGetLastError());
+        uint32_t nActive = N, nodesMade = 0;
+        int rounds = 0;
+        for (; nActive > G && rounds < kPlocMaxRounds; ++rounds) {
+            const int in = rounds & 1, out = in ^ 1;
+            hipLaunchKernelGGL(plocNearestKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, radius, dCl[in], dClBox[in], dNn);
+            HIP_TRY(c, hipGetLastError());
+            hipLaunchKernelGGL(plocFlagKernel, dim3(blocksFor(size_t(nActive) + 1)), dim3(256), 0, stream, nActive, dNn, dFlags);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dPlaceTemp, placeBytes, dFlags, dPlaces, int(nActive) + 1, stream));
+            hipLaunchKernelGGL(plocCommitKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, N, nodesMade, dNn, dFlags, dPlaces, dCl[in], dClBox[in], dCl[out],
+                dClBox[out], dLeft, dRight, dNodeBox, dCount, dParentInt, dParentLeaf, max_leaf, dCost, dCutWord);
+            HIP_TRY(c, hipGetLastError());
+            unsigned long long totals = 0;
+            HIP_TRY(c, hipMemcpyAsync(&totals, dPlaces + nActive, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipStreamSynchronize(stream));
+            const uint32_t stay = uint32_t(totals & 0xFFFFFFFFull), merges = uint32_t(totals >> 32);
+            if (merges == 0u || stay + merges != nActive || stay < G)
+                return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: a round of the clustering merged nothing (internal error)");
+            nodesMade += merges;
+            nActive = stay;
+        }
+        if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG"))
+            std::fprintf(stderr, "bvh_build: clustering, radius %d: %d rounds, %u nodes, %u clusters left for %u groups\n", radius, rounds, nodesMade, nActive, G);
+        if (nActive == G) {
+            uint32_t error = 0;
+            hipLaunchKernelGGL(plocRootsKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, G, dCl[rounds & 1], dGroupRoot);
+            HIP_TRY(c, hipGetLastError());
+            hipLaunchKernelGGL(plocPositionKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, uint32_t(rounds) + 1u, dGroupOf, dOffsets, dLeft, dRight, dParentInt, dParentLeaf,
+                dCount, dNewPos, dError);
+            HIP_TRY(c, hipGetLastError());
+            hipLaunchKernelGGL(plocRangesKernel, dim3(blocksFor(nodesMade)), dim3(256), 0, stream, nodesMade, N, uint32_t(rounds) + 1u, dLeft, dRight, dCount, dNewPos, dLo, dHi,
+                dLeft2, dRight2, dError);
+            HIP_TRY(c, hipGetLastError());
+            hipLaunchKernelGGL(plocReorderKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dNewPos, dOrder2);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(&error, dError, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(c, hipStreamSynchronize(stream));
+            if (error != 0u)
+                return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: the clustered tree is not a tree (internal error)");
+            dLeft = dLeft2;
+            dRight = dRight2;
+            dOrder = dOrder2;
+        } else {
+            // too many rounds (a chain of merges: nothing seen on real geometry): the radix tree instead
+            clustered = false;
+            HIP_TRY(c, hipMemsetAsync(dParentInt, 0xFF, size_t(N) * 4, stream));
+            HIP_TRY(c, hipMemsetAsync(dParentLeaf, 0xFF, size_t(N) * 4, stream));
+            HIP_TRY(c, hipMemsetAsync(dGroupRoot, 0xFF, n_groups * 4, stream));
+        }
+    }
+    if (N > 1u && !clustered) {
         hipLaunchKernelGGL(hierarchyKernel, dim3(blocksFor(N - 1u)), dim3(256), 0, stream, dKeysSorted, N, dGroupOf, dOffsets, dLeft, dRight, dLo, dHi, dParentInt,
             dParentLeaf, dGroupRoot);
         HIP_TRY(c, hipGetLastError());

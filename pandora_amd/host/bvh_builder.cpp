@@ -499,12 +499,20 @@ struct Bvh8Builder {
                 std::fprintf(stderr, "reinsertion pass %d: inner area / root area = %.3f\n", pass + 1, sum / bins[size_t(root)].box.halfArea());
             }
         }
-        // renumber parent first, reorder the objects by the new tree's leaf order
+        relinearise(links, root);
+    }
+
+    // renumber parent first, reorder the objects by the tree's leaf order
+    void relinearise(const std::vector<Link>& links, int root)
+    {
+        const size_t n = bins.size();
         std::vector<Bin> out;
         out.reserve(n);
         std::vector<Item> ordered;
         ordered.reserve(items.size());
-        const size_t base = bins[0].begin;
+        size_t base = items.size();
+        for (const Bin& b : bins)
+            base = std::min(base, b.begin);
         for (size_t i = 0; i < base; ++i)
             ordered.push_back(items[i]);
         std::vector<int> newIndex(n, -1);

@@ -22,6 +22,13 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(params=["ploc", "lbvh"], autouse=True)
+def binary_tree(request, monkeypatch):
+    """Every test with both binary trees under the collapse: locally-ordered clustering (the default) and the radix tree."""
+    monkeypatch.setenv("PANDORA_BVH8_DEVICE_TREE", request.param)
+    return request.param
+
+
 def check_tree(hb, mesh, max_leaf):
     """Every triangle of the group exactly once, handles in range, children packed at the front, stored child boxes equal to the
     exact bounds below them, absent children zero, octant words by the reference's rule. -> depth"""
