@@ -852,6 +852,106 @@ struct DeviceBuild { // what a build leaves on the device (freed with the object
     std::vector<uint32_t> nodeCount, depth, failed, nodeBase;
 };
 
+struct ClusterTreeArrays { // in: order, primBox, groupOf, offsets; out (N each): the tree, its boxes, ranges, tables; left / right / order are replaced
+    uint32_t* order;
+    const Box6* primBox;
+    const uint32_t* groupOf;
+    const unsigned long long* offsets;
+    uint32_t *left, *right, *lo, *hi;
+    Box6* nodeBox;
+    uint32_t *parentInt, *parentLeaf, *groupRoot;
+    float* cost;
+    uint32_t* cutWord;
+};
+
+// Steps 3b + 4b on the context's stream. *done = false: not built (one triangle per group, switched off by the environment, or
+// more than kPlocMaxRounds rounds) and the parent / root arrays are as they were before the call; the caller builds the radix tree.
+int clusterTree(pgpu_ctx* c, Scratch& mem, uint32_t N, uint32_t G, uint32_t max_leaf, ClusterTreeArrays& t, bool* done)
+{
+    hipStream_t stream = c->stream;
+    *done = false;
+    int radius = 3;
+    if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_PLOC_RADIUS"))
+        radius = std::max(1, std::min(64, std::atoi(e)));
+    const char* treeEnv = std::getenv("PANDORA_BVH8_DEVICE_TREE");
+    if (N <= 1u || N <= G || (treeEnv && std::strcmp(treeEnv, "lbvh") == 0))
+        return PGPU_OK;
+    PlocCluster* dCl[2] = { nullptr, nullptr };
+    Box6* dClBox[2] = { nullptr, nullptr };
+    uint32_t *dNn = nullptr, *dCount = nullptr, *dNewPos = nullptr, *dOrder2 = nullptr, *dLeft2 = nullptr, *dRight2 = nullptr, *dError = nullptr;
+    unsigned long long *dFlags = nullptr, *dPlaces = nullptr;
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(c, mem.alloc(&dCl[k], N));
+        HIP_TRY(c, mem.alloc(&dClBox[k], N));
+    }
+    HIP_TRY(c, mem.alloc(&dNn, N));
+    HIP_TRY(c, mem.alloc(&dCount, N));
+    HIP_TRY(c, mem.alloc(&dNewPos, N));
+    HIP_TRY(c, mem.alloc(&dOrder2, N));
+    HIP_TRY(c, mem.alloc(&dLeft2, N));
+    HIP_TRY(c, mem.alloc(&dRight2, N));
+    HIP_TRY(c, mem.alloc(&dError, 1));
+    HIP_TRY(c, mem.alloc(&dFlags, size_t(N) + 1));
+    HIP_TRY(c, mem.alloc(&dPlaces, size_t(N) + 1));
+    size_t placeBytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, placeBytes, dFlags, dPlaces, int(N) + 1, stream));
+    unsigned char* dPlaceTemp = nullptr;
+    HIP_TRY(c, mem.alloc(&dPlaceTemp, placeBytes));
+    HIP_TRY(c, hipMemsetAsync(dError, 0, 4, stream));
+    hipLaunchKernelGGL(plocInitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, t.order, t.primBox, t.groupOf, t.offsets, dCl[0], dClBox[0]);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t nActive = N, nodesMade = 0;
+    int rounds = 0;
+    for (; nActive > G && rounds < kPlocMaxRounds; ++rounds) {
+        const int in = rounds & 1, out = in ^ 1;
+        hipLaunchKernelGGL(plocNearestKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, radius, dCl[in], dClBox[in], dNn);
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(plocFlagKernel, dim3(blocksFor(size_t(nActive) + 1)), dim3(256), 0, stream, nActive, dNn, dFlags);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dPlaceTemp, placeBytes, dFlags, dPlaces, int(nActive) + 1, stream));
+        hipLaunchKernelGGL(plocCommitKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, N, nodesMade, dNn, dFlags, dPlaces, dCl[in], dClBox[in], dCl[out],
+            dClBox[out], t.left, t.right, t.nodeBox, dCount, t.parentInt, t.parentLeaf, max_leaf, t.cost, t.cutWord);
+        HIP_TRY(c, hipGetLastError());
+        unsigned long long totals = 0;
+        HIP_TRY(c, hipMemcpyAsync(&totals, dPlaces + nActive, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(c, hipStreamSynchronize(stream));
+        const uint32_t stay = uint32_t(totals & 0xFFFFFFFFull), merges = uint32_t(totals >> 32);
+        if (merges == 0u || stay + merges != nActive || stay < G)
+            return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: a round of the clustering merged nothing (internal error)");
+        nodesMade += merges;
+        nActive = stay;
+    }
+    if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG"))
+        std::fprintf(stderr, "bvh_build: clustering, radius %d: %d rounds, %u nodes, %u clusters left for %u groups\n", radius, rounds, nodesMade, nActive, G);
+    if (nActive != G) {
+        // too many rounds (a chain of merges: nothing seen on real geometry): the radix tree instead
+        HIP_TRY(c, hipMemsetAsync(t.parentInt, 0xFF, size_t(N) * 4, stream));
+        HIP_TRY(c, hipMemsetAsync(t.parentLeaf, 0xFF, size_t(N) * 4, stream));
+        HIP_TRY(c, hipMemsetAsync(t.groupRoot, 0xFF, size_t(G) * 4, stream));
+        return PGPU_OK;
+    }
+    uint32_t error = 0;
+    hipLaunchKernelGGL(plocRootsKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, G, dCl[rounds & 1], t.groupRoot);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(plocPositionKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, uint32_t(rounds) + 1u, t.groupOf, t.offsets, t.left, t.right, t.parentInt, t.parentLeaf,
+        dCount, dNewPos, dError);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(plocRangesKernel, dim3(blocksFor(nodesMade)), dim3(256), 0, stream, nodesMade, N, uint32_t(rounds) + 1u, t.left, t.right, dCount, dNewPos, t.lo, t.hi,
+        dLeft2, dRight2, dError);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(plocReorderKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, t.order, dNewPos, dOrder2);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&error, dError, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    if (error != 0u)
+        return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: the clustered tree is not a tree (internal error)");
+    t.left = dLeft2;
+    t.right = dRight2;
+    t.order = dOrder2;
+    *done = true;
+    return PGPU_OK;
+}
+
 // Validates the arguments and runs steps 1-6; ev0 is recorded behind the uploads (the caller records ev1).
 int buildOnDevice(pgpu_ctx* c, const float* positions, size_t n_vertices, const uint32_t* indices, size_t n_triangles, const uint32_t* group_prims,
     const uint64_t* group_offsets, size_t n_groups, uint32_t max_leaf, bool persistentNodes, DeviceBuild& b)
@@ -968,85 +1068,15 @@ int buildOnDevice(pgpu_ctx* c, const float* positions, size_t n_vertices, const 
     // the binary tree: locally-ordered clustering (PANDORA_BVH8_DEVICE_TREE=ploc, the default; PANDORA_BVH8_DEVICE_PLOC_RADIUS places to
     // either side, default 3) or the radix tree over the keys (=lbvh; also what is built if the clustering does not finish in
     // kPlocMaxRounds rounds, which bounds the depth of its tree)
-    int radius = 3;
-    if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_PLOC_RADIUS"))
-        radius = std::max(1, std::min(64, std::atoi(e)));
-    const char* treeEnv = std::getenv("PANDORA_BVH8_DEVICE_TREE");
-    bool clustered = N > 1u && N > G && !(treeEnv && std::strcmp(treeEnv, "lbvh") == 0);
-    if (clustered) {
-        PlocCluster* dCl[2] = { nullptr, nullptr };
-        Box6* dClBox[2] = { nullptr, nullptr };
-        uint32_t *dNn = nullptr, *dCount = nullptr, *dNewPos = nullptr, *dOrder2 = nullptr, *dLeft2 = nullptr, *dRight2 = nullptr, *dError = nullptr;
-        unsigned long long *dFlags = nullptr, *dPlaces = nullptr;
-        for (int k = 0; k < 2; ++k) {
-            HIP_TRY(c, mem.alloc(&dCl[k], N));
-            HIP_TRY(c, mem.alloc(&dClBox[k], N));
-        }
-        HIP_TRY(c, mem.alloc(&dNn, N));
-        HIP_TRY(c, mem.alloc(&dCount, N));
-        HIP_TRY(c, mem.alloc(&dNewPos, N));
-        HIP_TRY(c, mem.alloc(&dOrder2, N));
-        HIP_TRY(c, mem.alloc(&dLeft2, N));
-        HIP_TRY(c, mem.alloc(&dRight2, N));
-        HIP_TRY(c, mem.alloc(&dError, 1));
-        HIP_TRY(c, mem.alloc(&dFlags, size_t(N) + 1));
-        HIP_TRY(c, mem.alloc(&dPlaces, size_t(N) + 1));
-        size_t placeBytes = 0;
-        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, placeBytes, dFlags, dPlaces, int(N) + 1, stream));
-        unsigned char* dPlaceTemp = nullptr;
-        HIP_TRY(c, mem.alloc(&dPlaceTemp, placeBytes));
-        HIP_TRY(c, hipMemsetAsync(dError, 0, 4, stream));
-        hipLaunchKernelGGL(plocInitKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dPrimBox, dGroupOf, dOffsets, dCl[0], dClBox[0]);
-        HIP_TRY(c, hipGetLastError());
-        uint32_t nActive = N, nodesMade = 0;
-        int rounds = 0;
-        for (; nActive > G && rounds < kPlocMaxRounds; ++rounds) {
-            const int in = rounds & 1, out = in ^ 1;
-            hipLaunchKernelGGL(plocNearestKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, radius, dCl[in], dClBox[in], dNn);
-            HIP_TRY(c, hipGetLastError());
-            hipLaunchKernelGGL(plocFlagKernel, dim3(blocksFor(size_t(nActive) + 1)), dim3(256), 0, stream, nActive, dNn, dFlags);
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(dPlaceTemp, placeBytes, dFlags, dPlaces, int(nActive) + 1, stream));
-            hipLaunchKernelGGL(plocCommitKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, N, nodesMade, dNn, dFlags, dPlaces, dCl[in], dClBox[in], dCl[out],
-                dClBox[out], dLeft, dRight, dNodeBox, dCount, dParentInt, dParentLeaf, max_leaf, dCost, dCutWord);
-            HIP_TRY(c, hipGetLastError());
-            unsigned long long totals = 0;
-            HIP_TRY(c, hipMemcpyAsync(&totals, dPlaces + nActive, 8, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipStreamSynchronize(stream));
-            const uint32_t stay = uint32_t(totals & 0xFFFFFFFFull), merges = uint32_t(totals >> 32);
-            if (merges == 0u || stay + merges != nActive || stay < G)
-                return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: a round of the clustering merged nothing (internal error)");
-            nodesMade += merges;
-            nActive = stay;
-        }
-        if (std::getenv("PANDORA_BVH8_DEVICE_DEBUG"))
-            std::fprintf(stderr, "bvh_build: clustering, radius %d: %d rounds, %u nodes, %u clusters left for %u groups\n", radius, rounds, nodesMade, nActive, G);
-        if (nActive == G) {
-            uint32_t error = 0;
-            hipLaunchKernelGGL(plocRootsKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, G, dCl[rounds & 1], dGroupRoot);
-            HIP_TRY(c, hipGetLastError());
-            hipLaunchKernelGGL(plocPositionKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, uint32_t(rounds) + 1u, dGroupOf, dOffsets, dLeft, dRight, dParentInt, dParentLeaf,
-                dCount, dNewPos, dError);
-            HIP_TRY(c, hipGetLastError());
-            hipLaunchKernelGGL(plocRangesKernel, dim3(blocksFor(nodesMade)), dim3(256), 0, stream, nodesMade, N, uint32_t(rounds) + 1u, dLeft, dRight, dCount, dNewPos, dLo, dHi,
-                dLeft2, dRight2, dError);
-            HIP_TRY(c, hipGetLastError());
-            hipLaunchKernelGGL(plocReorderKernel, dim3(blocksFor(N)), dim3(256), 0, stream, N, dOrder, dNewPos, dOrder2);
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipMemcpyAsync(&error, dError, 4, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(c, hipStreamSynchronize(stream));
-            if (error != 0u)
-                return fail(c, PGPU_ERR_HIP, "pgpu_build_bvh8_device: the clustered tree is not a tree (internal error)");
-            dLeft = dLeft2;
-            dRight = dRight2;
-            dOrder = dOrder2;
-        } else {
-            // too many rounds (a chain of merges: nothing seen on real geometry): the radix tree instead
-            clustered = false;
-            HIP_TRY(c, hipMemsetAsync(dParentInt, 0xFF, size_t(N) * 4, stream));
-            HIP_TRY(c, hipMemsetAsync(dParentLeaf, 0xFF, size_t(N) * 4, stream));
-            HIP_TRY(c, hipMemsetAsync(dGroupRoot, 0xFF, n_groups * 4, stream));
-        }
+    bool clustered = false;
+    {
+        ClusterTreeArrays t { dOrder, dPrimBox, dGroupOf, dOffsets, dLeft, dRight, dLo, dHi, dNodeBox, dParentInt, dParentLeaf, dGroupRoot, dCost, dCutWord };
+        const int rt = clusterTree(c, mem, N, G, max_leaf, t, &clustered);
+        if (rt != PGPU_OK)
+            return rt;
+        dLeft = t.left;
+        dRight = t.right;
+        dOrder = t.order;
     }
     if (N > 1u && !clustered) {
         hipLaunchKernelGGL(hierarchyKernel, dim3(blocksFor(N - 1u)), dim3(256), 0, stream, dKeysSorted, N, dGroupOf, dOffsets, dLeft, dRight, dLo, dHi, dParentInt,
