@@ -63,12 +63,13 @@ int pgpu_host_bvh8_depth(const pgpu_host_bvh8*); /* nested inner nodes on the lo
 void pgpu_host_bvh8_free(pgpu_host_bvh8*);
 /* The BVH8s of many triangle groups (batching points) at once, built on the GPU of `ctx` (pandora_amd/csrc/bvh_build.hip; the
  * reference builds one tree per batching point with Embree on the CPU, wive_bvh8_build8_impl.h:87-104, offline_bvh_cache.cpp:273-309):
- * Morton order per group, one binary radix tree over all groups, boxes and the collapse's cost tables bottom-up, collapse into 8-wide
+ * Morton order per group, one binary tree over all groups by locally-ordered clustering along that order (boxes and the collapse's
+ * cost tables made with the nodes; PANDORA_BVH8_DEVICE_TREE=lbvh: a radix tree with a bottom-up pass instead), collapse into 8-wide
  * nodes by those tables, the reference's 256-byte nodes and octant words written by the device. Group g = triangles group_prims[group_offsets[g] .. group_offsets[g+1])
  * of the mesh (host arrays; offsets start at 0 and increase); out[g] receives the same kind of object pgpu_build_bvh8 returns
- * (leaf object j of a group = its j-th triangle) and is freed with pgpu_host_bvh8_free. Trees are of LBVH quality (on the
- * benchmark atrium 10 % more node visits per diffuse ray than pgpu_build_bvh8's, 7 % fewer rays per second) and cost 11 ms of GPU
- * time for 11.4 M triangles in 256 groups (the host builder: 0.4 s on 16 threads). Node numbering is breadth first per group and does
+ * (leaf object j of a group = its j-th triangle) and is freed with pgpu_host_bvh8_free. On the benchmark atrium a diffuse
+ * ray pays 6 % more node and leaf visits in such a tree than in pgpu_build_bvh8's (4 % fewer rays per second); the build costs 10 ms
+ * of GPU time for 11.4 M triangles in 256 groups (the host builder: 0.6 s on 16 threads). Node numbering is breadth first per group and does
  * not depend on the run or on the other groups of the call. A group whose device tree would nest deeper than 12 inner nodes is
  * built by pgpu_build_bvh8 instead; *n_host_built (may be NULL) says how many were.
  * pgpu_last_kernel_ms = device time of the build. max_leaf in 1..4, at most 2^20 groups and 2^31 - 2 triangles in all. */
