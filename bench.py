@@ -39,6 +39,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MISS = np.uint32(0xFFFFFFFF)
 
 
+def builder_detail(builder: str) -> str:
+    """What built the BVH8s, with the settings the library reads from the environment."""
+    if builder == "host":
+        if os.environ.get("PANDORA_BVH8_BUILDER") == "greedy":
+            return "host: greedy top-down binned SAH"
+        return "host: binary SAH tree, %s reinsertion passes, collapsed by dynamic programming" % os.environ.get("PANDORA_BVH8_REINSERT", "10")
+    if os.environ.get("PANDORA_BVH8_DEVICE_TREE") == "lbvh":
+        return "device: radix tree over Morton keys, collapsed by cost tables"
+    return "device: locally-ordered clustering (radius %s) over Morton order, collapsed by cost tables" % os.environ.get("PANDORA_BVH8_DEVICE_PLOC_RADIUS", "3")
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,7 +240,7 @@ def run_single(args, pa, torch, ctx, dev, rank):
                 issue = tj.get("issue")  # what actually bounds the kernel: VALU issue slots used, lanes active, waves waiting (same PMC passes)
         config = {"workload": "configs[1]: Sponza-class synthetic atrium (%d triangles), in-core single-level WiVe BVH8, R-%s %s-hit" % (mesh.n_tris, args.rays, args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "bvh8_nodes": hb.n_nodes, "bvh8_depth": hb.depth,
-                  "bvh8_builder": args.builder, "bvh8_build_s": build_s, "bvh8_build_device_ms": build_device_ms, "bvh8_built_and_uploaded_s": ready_s,
+                  "bvh8_builder": args.builder, "bvh8_builder_detail": builder_detail(args.builder), "bvh8_build_s": build_s, "bvh8_build_device_ms": build_device_ms, "bvh8_built_and_uploaded_s": ready_s,
                   "triangle_test": args.tri, "hit_fraction": hit_frac, "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src, "issue": issue, "kernel": "bvh8TraceKernel", "kernel_ms": k_ms,
@@ -312,7 +323,7 @@ def run_two_level(args, pa, torch, ctx, dev, rank):
                    "gpu_matches_bit_exact": bool(same)}
         config = {"workload": "configs[2]: San-Miguel-class synthetic city (%d triangles), two-level: PauseableBVH4 over %d batching points with %d^3 SVDAG early-out%s + per-point WiVe BVH8, R-diffuse %s-hit" % (mesh.n_tris, tl.n_leaves, args.svdag, "" if args.svdag_policy == "always" else " for non-resident points only (here: none)", args.kind),
                   "rays_per_gpu": n, "triangles": mesh.n_tris, "batching_points": tl.n_leaves, "triangle_test": args.tri,
-                  "bvh8_builder": args.builder, "cut": args.cut, "scene_build_s": build_s, "scene_built_and_uploaded_s": ready_s,
+                  "bvh8_builder": args.builder, "bvh8_builder_detail": builder_detail(args.builder), "cut": args.cut, "scene_build_s": build_s, "scene_built_and_uploaded_s": ready_s,
                   "rounds": cnt["rounds"], "leaf_visits_per_ray": cnt["leaf_visits"] / n, "svdag_tests": cnt["svdag_tests"], "svdag_culled": cnt["svdag_culled"],
                   "parallelism": "rays sharded over %d GPU(s), scene replicated" % world}
         # memory-side bytes per step from rocprofv3 PMC passes of this same command (tools/pmc_two_level_traffic.py), quoted as for
