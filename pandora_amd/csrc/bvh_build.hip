@@ -337,6 +337,7 @@ struct PlocCluster {
     uint32_t ref;   // a sorted triangle (| kLeafRef) or a node
     uint32_t group;
     uint32_t first; // position of its first triangle within the group
+    uint32_t count; // triangles below
 };
 
 __global__ void __launch_bounds__(256) plocInitKernel(uint32_t n, const uint32_t* __restrict__ order, const Box6* __restrict__ primBox, const uint32_t* __restrict__ groupOf,
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(256) plocInitKernel(uint32_t n, const uint32_t
     if (p >= n)
         return;
     const uint32_t g = groupOf[p];
-    cl[p] = PlocCluster { p | kLeafRef, g, p - uint32_t(offsets[g]) };
+    cl[p] = PlocCluster { p | kLeafRef, g, p - uint32_t(offsets[g]), 1u };
     cBox[p] = primBox[order[p]];
 }
 
@@ -435,7 +436,7 @@ __global__ void __launch_bounds__(256) plocCommitKernel(uint32_t nActive, uint32
         left[node] = l;
         right[node] = r;
         nodeBox[node] = box;
-        const uint32_t cnt = ((l & kLeafRef) ? 1u : count[l]) + ((r & kLeafRef) ? 1u : count[r]);
+        const uint32_t cnt = me.count + clIn[j].count;
         count[node] = cnt;
         if (l & kLeafRef)
             parentLeaf[l & ~kLeafRef] = node;
@@ -456,6 +457,7 @@ __global__ void __launch_bounds__(256) plocCommitKernel(uint32_t nActive, uint32
                 cost[size_t(node) * 8u + (q - 1)] = cj[q];
         }
         me.ref = node;
+        me.count = cnt;
     }
     clOut[place] = me;
     boxOut[place] = box;
