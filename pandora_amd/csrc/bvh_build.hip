@@ -875,6 +875,9 @@ int clusterTree(pgpu_ctx* c, Scratch& mem, uint32_t N, uint32_t G, uint32_t max_
     int radius = 3;
     if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_PLOC_RADIUS"))
         radius = std::max(1, std::min(64, std::atoi(e)));
+    int maxRounds = kPlocMaxRounds;
+    if (const char* e = std::getenv("PANDORA_BVH8_DEVICE_PLOC_ROUNDS")) // (tests: a budget the clustering cannot meet, so that the radix tree takes over)
+        maxRounds = std::max(1, std::min(kPlocMaxRounds, std::atoi(e)));
     const char* treeEnv = std::getenv("PANDORA_BVH8_DEVICE_TREE");
     if (N <= 1u || N <= G || (treeEnv && std::strcmp(treeEnv, "lbvh") == 0))
         return PGPU_OK;
@@ -904,7 +907,7 @@ int clusterTree(pgpu_ctx* c, Scratch& mem, uint32_t N, uint32_t G, uint32_t max_
     HIP_TRY(c, hipGetLastError());
     uint32_t nActive = N, nodesMade = 0;
     int rounds = 0;
-    for (; nActive > G && rounds < kPlocMaxRounds; ++rounds) {
+    for (; nActive > G && rounds < maxRounds; ++rounds) {
         const int in = rounds & 1, out = in ^ 1;
         hipLaunchKernelGGL(plocNearestKernel, dim3(blocksFor(nActive)), dim3(256), 0, stream, nActive, radius, dCl[in], dClBox[in], dNn);
         HIP_TRY(c, hipGetLastError());

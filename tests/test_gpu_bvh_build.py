@@ -367,3 +367,26 @@ def test_both_collapses_give_valid_trees_and_the_tables_give_the_smaller_one(ctx
     (second,), host_built = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx)
     check_tree(second, mesh, 4)
     assert second.depth <= by_tables.depth - 1 or host_built == 1
+
+
+def test_a_clustering_that_does_not_finish_leaves_the_build_to_the_radix_tree(ctx, monkeypatch, binary_tree):
+    """More rounds than the budget (1024; here 5, by PANDORA_BVH8_DEVICE_PLOC_ROUNDS): the radix tree is built instead, and the result
+    is byte for byte what PANDORA_BVH8_DEVICE_TREE=lbvh gives."""
+    if binary_tree != "ploc":
+        pytest.skip("the radix tree has no rounds")
+    mesh = pa.scenes.g_city(2, 3000)
+    group_of, ng = pa.accel.partition_prims(mesh.pos, mesh.idx, 2000)
+    groups = [np.nonzero(group_of == g)[0].astype(np.uint32) for g in range(ng)]
+    monkeypatch.setenv("PANDORA_BVH8_DEVICE_PLOC_ROUNDS", "5")
+    cut_short, host_built = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, groups)
+    assert host_built == 0
+    monkeypatch.delenv("PANDORA_BVH8_DEVICE_PLOC_ROUNDS")
+    clustered, _ = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, groups)
+    monkeypatch.setenv("PANDORA_BVH8_DEVICE_TREE", "lbvh")
+    radix, _ = pa.accel.build_bvh8_device(ctx, mesh.pos, mesh.idx, groups)
+    differs = 0
+    for a, b, c, g in zip(cut_short, radix, clustered, groups):
+        check_tree(a, mesh, 4)
+        assert np.array_equal(a.nodes.view(np.uint32), b.nodes.view(np.uint32)) and np.array_equal(a.leaf_idx, b.leaf_idx)
+        differs += a.n_nodes != c.n_nodes or not np.array_equal(a.leaf_idx, c.leaf_idx)
+    assert differs > 0  # (the clustered trees are other trees)
