@@ -108,7 +108,7 @@ Box boundsOf(const std::vector<Item>& items, size_t b, size_t e)
 // Binned SAH split of items[begin,end); falls back to an index median when every centroid coincides.
 // forceMedian gives the balanced split used when a subtree would otherwise exceed the depth budget.
 // quantum != 0: a side weighs ceil(objects / quantum) instead of its objects (the scene cut, pgpu_partition_prims).
-size_t splitPart(std::vector<Item>& items, size_t begin, size_t end, bool forceMedian, size_t quantum = 0)
+size_t splitPart(std::vector<Item>& items, size_t begin, size_t end, bool forceMedian, size_t quantum = 0, float mix = 0.0f)
 {
     const size_t n = end - begin;
     Box cb;
@@ -146,7 +146,7 @@ size_t splitPart(std::vector<Item>& items, size_t begin, size_t end, bool forceM
                 cnt += bc[b];
                 if (cnt == 0 || rightCount[b + 1] == 0)
                     continue;
-                auto weight = [&](size_t c) { return quantum ? float((c + quantum - 1) / quantum) : float(c); };
+                auto weight = [&](size_t c) { return quantum ? float((c + quantum - 1) / quantum) + mix * float(c) / float(quantum) : float(c); };
                 const float cost = acc.halfArea() * weight(cnt) + rightArea[b + 1] * weight(rightCount[b + 1]);
                 if (cost < bestCost) {
                     bestCost = cost;
@@ -978,12 +978,14 @@ int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32
     std::vector<Range> leaves;
     size_t busy = 0;
     const size_t grain = std::max(max_prims, n_triangles / (8 * size_t(nThreads)));
-    // A side of a split is weighed by the batching points it will need at least, ceil(triangles / max_prims), not by its
-    // triangles: what a ray pays at this level is a visit per batching point it enters, so the cut looks for few, full points
-    // with small boxes (PANDORA_CUT_OBJECTIVE=sah: surface x triangles, the cut of rounds 1-2 -- a quarter more points, 10 % more
-    // visits per ray on the benchmark city).
+    // PANDORA_CUT_OBJECTIVE=points: a side of a split weighs the batching points it will need at least, ceil(triangles / max_prims),
+    // instead of its triangles (=mixed[f]: that count + f x triangles / max_prims). Fewer, fuller, longer points: on the benchmark
+    // city 208 instead of 256, 10 % fewer points entered per ray of the bench's diffuse batch and 7 % more per ray of a frame seen
+    // from the street, the same summed surface either way -- which is why surface x triangles stays the default.
     const char* objective = std::getenv("PANDORA_CUT_OBJECTIVE");
-    const size_t quantum = objective && std::strcmp(objective, "sah") == 0 ? 0 : max_prims;
+    const bool byPoints = objective && (std::strcmp(objective, "points") == 0 || std::strncmp(objective, "mixed", 5) == 0);
+    const size_t quantum = byPoints ? max_prims : 0;
+    const float mix = byPoints && objective[0] == 'm' ? (objective[5] ? float(std::atof(objective + 5)) : 1.0f) : 0.0f;
     auto worker = [&] {
         std::vector<Range> local, mine;
         std::unique_lock<std::mutex> lk(mu);
@@ -1003,7 +1005,7 @@ int pgpu_partition_prims(const float* positions, size_t n_vertices, const uint32
                         mine.push_back({ b, e });
                     continue;
                 }
-                const size_t m = splitPart(items, b, e, false, quantum);
+                const size_t m = splitPart(items, b, e, false, quantum, mix);
                 if (e - m > grain) {
                     {
                         std::lock_guard<std::mutex> g(mu);
