@@ -210,6 +210,23 @@ def test_partition_is_the_same_on_every_run():
         assert ng2 == ng and np.array_equal(again, first)
 
 
+@pytest.mark.parametrize("objective", ["sah", "points", "mixed0.5"])
+def test_cut_objectives_are_partitions_within_the_budget(monkeypatch, objective):
+    """PANDORA_CUT_OBJECTIVE: a side of a split weighed by its triangles (default), by the batching points it needs, or a mix --
+    each a partition within the budget, the same on every run; by points there are no more points than by triangles."""
+    mesh = pa.scenes.g_city(3, 20000)
+    monkeypatch.setenv("PANDORA_CUT_OBJECTIVE", objective)
+    g, ng = pa.accel.partition_prims(mesh.pos, mesh.idx, 4096)
+    counts = np.bincount(g, minlength=ng)
+    assert g.size == mesh.n_tris and counts.min() >= 1 and counts.max() <= 4096 and ng >= -(-mesh.n_tris // 4096)
+    again, ng2 = pa.accel.partition_prims(mesh.pos, mesh.idx, 4096)
+    assert ng2 == ng and np.array_equal(again, g)
+    if objective != "sah":
+        monkeypatch.setenv("PANDORA_CUT_OBJECTIVE", "sah")
+        _, ng_sah = pa.accel.partition_prims(mesh.pos, mesh.idx, 4096)
+        assert ng <= ng_sah
+
+
 def test_collapsed_construction_against_the_greedy_one(monkeypatch):
     """The default construction (binary SAH tree collapsed into 8-wide nodes by dynamic programming) and the greedy top-down one
     (PANDORA_BVH8_BUILDER=greedy) hold the same triangles: same nearest distance through the oracle (to the last bit but for a few ties); the collapsed
