@@ -91,7 +91,7 @@ def parse_args():
     ap.add_argument("--top-variant", type=int, default=0, help="two-level: pgpu_set_top_variant (0 automatic, 1 lockstep waves, 2 independent lanes, 3 lockstep first episode then lanes)")
     ap.add_argument("--batch-parts", type=int, default=0, help="two-level: pgpu_set_batch_parts (0 = the library's default: two parts from 2^21 rays on; 1 = the batch as one)")
     ap.add_argument("--builder", choices=["host", "device", "resident"], default="host",
-                    help="bottom-level BVH8 construction: host = binary SAH tree collapsed by dynamic programming (the default, the best trees), device = pgpu_build_bvh8_device (LBVH on the GPU, every batching point in one pass, trees returned to the host and uploaded like the host builder's), resident = pgpu_build_upload_bvh8_device (the same trees, never leaving the GPU)")
+                    help="bottom-level BVH8 construction: host = binary SAH tree collapsed by dynamic programming (the default, the best trees), device = pgpu_build_bvh8_device (locally-ordered clustering along the Morton order on the GPU, every batching point in one pass, trees returned to the host and uploaded like the host builder's), resident = pgpu_build_upload_bvh8_device (the same trees, never leaving the GPU)")
     ap.add_argument("--cut", choices=["host", "device"], default="host", help="two-level: the cut into batching points: host = binned-SAH BVH2 cut (pgpu_partition_prims, the default), device = the same rule on an LBVH built on the GPU (pgpu_partition_prims_device)")
     ap.add_argument("--dry", action="store_true", help="no GPU: the ranks only meet (gloo) and reduce made-up figures; checks the launch path")
     return ap.parse_args()
