@@ -586,9 +586,10 @@ struct Bvh8Builder {
                 }
             }
             const float asInner = area * costInner + bestKids;
-            b.inner1 = asInner < asLeaf ? 1 : 0;
+            // (more than a leaf holds is a node whatever the numbers say: surfaces that overflow or are not numbers compare false)
+            b.inner1 = (asLeaf == FLT_MAX || asInner < asLeaf) ? 1 : 0;
             b.kLeft = bestK;
-            b.cost[1] = std::min(asInner, asLeaf);
+            b.cost[1] = b.inner1 ? asInner : asLeaf;
             b.cut[1] = 0;
             for (int j = 2; j <= 8; ++j) {
                 float best = b.cost[1];

@@ -110,6 +110,33 @@ def test_bvh8_depth_budget_on_degenerate_input():
     assert hb.depth <= 12
 
 
+@pytest.mark.parametrize("case", ["nan_some", "inf_some", "coincident", "huge", "line", "nan_all"])
+def test_bvh8_is_a_tree_whatever_the_vertices(case):
+    """Vertices that are not numbers, infinite, all the same, so large that surfaces overflow, or on one line: the costs of the
+    collapse stop comparing, the result is still a tree within the depth budget that holds every triangle once."""
+    rng = np.random.default_rng(1)
+    n = 3000
+    pos = rng.uniform(-10, 10, (3 * n, 3)).astype(np.float32)
+    if case == "nan_some":
+        pos[rng.integers(0, 3 * n, 200)] = np.nan
+    elif case == "inf_some":
+        pos[rng.integers(0, 3 * n, 200)] = np.inf
+    elif case == "coincident":
+        pos[:] = 1.0
+    elif case == "huge":
+        pos *= np.float32(1e30)
+    elif case == "line":
+        pos[:, 1:] = 0
+    elif case == "nan_all":
+        pos[:] = np.nan
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    for max_leaf in (1, 4):
+        hb = pa.accel.build_bvh8(pos, idx, max_leaf=max_leaf)
+        nodes, slots, depth = _walk_bvh8(hb)
+        assert len(nodes) == hb.n_nodes and sorted(slots) == list(range(n)) and sorted(hb.leaf_idx.tolist()) == list(range(n))
+        assert depth == hb.depth and 7 * depth + 8 <= 96
+
+
 def test_top_bvh4_layout():
     rng = np.random.default_rng(3)
     for n in (2, 3, 4, 5, 17, 300):
