@@ -464,6 +464,11 @@ int pgpu_film_resolve(pgpu_ctx*, const unsigned long long* film, size_t n_pixels
  *                       BEFORE the BVHs are uploaded (36 bytes per leaf object; resident, non-instanced BVHs only).
  *   pgpu_splat_misses   PathIntegrator::rayMiss with one constant infinite light (:113-125) + Sensor::addPixelContribution: every
  *                       ray with obj = PGPU_MISS adds weight * sky to its pixel of the fixed-point film (pgpu_film_add's format).
+ *   pgpu_compact_paths  the end of a path (path_integrator.cpp:109-127: a path that missed or whose bounce failed spawns nothing):
+ *                       the rays with tnear <= tfar of a batch and their path states, in their order, at the front of another set of
+ *                       arrays (of at least n elements; not the input arrays); *n_live = how many. The next depth then traces n_live rays
+ *                       instead of n slots of which most are dead (a 4-bounce frame of the benchmark city: 15.6 M rays instead of
+ *                       33.5 M slots). Synchronises the stream (the count comes back to the host).
  * Arithmetic is binary32 in the reference's operation order; cos / sin of the disk mapping are the device's (<= 2 ulp from
  * glibc's cosf / sinf, which the reference calls): bounce directions agree with the CPU restatement to 1e-6, everything else
  * (camera rays, origins, rng streams, pixels, film) bit for bit. */
@@ -485,6 +490,8 @@ int pgpu_lambert_bounce(pgpu_ctx*, uint32_t bvh_id, const pgpu_rays* rays_in, co
     const pgpu_rays_out* rays, const pgpu_paths* paths, void* stream);
 int pgpu_splat_misses(pgpu_ctx*, unsigned long long* film, size_t n_pixels, const uint32_t* obj, const pgpu_paths* paths, size_t n, const float sky[3],
     void* stream);
+int pgpu_compact_paths(pgpu_ctx*, const pgpu_rays* rays_in, const pgpu_paths* paths_in, size_t n, const pgpu_rays_out* rays_out, const pgpu_paths* paths_out,
+    size_t* n_live, void* stream);
 
 /* Memory, copies and streams for hosts without HIP of their own (no counterpart in the reference, which never leaves host
  * memory; used by include/pandora_amd/gpu_acceleration_structure.hpp). pgpu_host_alloc gives pinned host memory: copies from

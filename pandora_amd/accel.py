@@ -529,8 +529,9 @@ class Context:
         n = int(rays.shape[1])
         assert rays.shape[0] == 8
         if self._is_torch(rays):
-            assert rays.is_cuda and rays.is_contiguous() and str(rays.dtype) == "torch.float32"
-            base, stride = rays.data_ptr(), n * 4
+            # (rows may be the front of longer rows: what compact_paths returns)
+            assert rays.is_cuda and str(rays.dtype) == "torch.float32" and (n == 0 or rays.stride(1) == 1) and rays.stride(0) >= n
+            base, stride = rays.data_ptr(), int(rays.stride(0)) * 4
         else:
             assert rays.dtype == np.float32 and rays.flags["C_CONTIGUOUS"]
             base, stride = rays.ctypes.data, n * 4
@@ -737,6 +738,20 @@ class Context:
         alb = (C.c_float * 3)(*[float(x) for x in albedo])
         _check(self._L.pgpu_lambert_bounce(self._h, capi.NO_BVH if bvh_id is None else bvh_id, C.byref(r_in), C.byref(h), n, alb, C.byref(r_out), C.byref(p), stream), self._h)
         return out
+
+    def compact_paths(self, rays, paths: dict, stream: int = 0):
+        """The paths that are still alive (tnear <= tfar), in their order: -> (rays [8, n_live], path state of n_live), views of
+        the front of new arrays of the old length. Waits for the stream (pgpu_compact_paths)."""
+        import torch
+        n = int(rays.shape[1])
+        out = torch.empty((8, n), dtype=torch.float32, device=rays.device)
+        pout = {k: torch.empty(n, dtype=v.dtype, device=v.device) for k, v in paths.items()}
+        r_in, _ = self._rays_struct(rays)
+        r_out, _ = self._rays_struct(out)
+        live = C.c_size_t(0)
+        _check(self._L.pgpu_compact_paths(self._h, C.byref(r_in), C.byref(self._paths_struct(paths)), n, C.byref(r_out), C.byref(self._paths_struct(pout)), C.byref(live), stream), self._h)
+        k = int(live.value)
+        return out[:, :k], {key: v[:k] for key, v in pout.items()}
 
     def splat_misses(self, film, obj, paths: dict, sky, stream: int = 0):
         p = self._paths_struct(paths)

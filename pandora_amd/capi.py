@@ -170,6 +170,7 @@ SYMBOLS = {
     "pgpu_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),
     "pgpu_lambert_bounce": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(Rays), C.POINTER(Hits), C.c_size_t, C.POINTER(C.c_float), C.POINTER(Rays), C.POINTER(Paths), C.c_void_p]),
     "pgpu_splat_misses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Paths), C.c_size_t, C.POINTER(C.c_float), C.c_void_p]),
+    "pgpu_compact_paths": (C.c_int, [C.c_void_p, C.POINTER(Rays), C.POINTER(Paths), C.c_size_t, C.POINTER(Rays), C.POINTER(Paths), C.POINTER(C.c_size_t), C.c_void_p]),
     "pgpu_film_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgpu_film_resolve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
 }

@@ -347,7 +347,7 @@ void pgpu_shutdown(pgpu_ctx* c)
     for (hipEvent_t e : { c->auxFork, c->auxJoin })
         if (e)
             (void)hipEventDestroy(e);
-    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->shardWork, &c->shardSend, &c->shardRecv, &c->spillB, &c->tableView })
+    for (DeviceBuffer* b : { &c->stageRays, &c->stageHits, &c->work, &c->spill, &c->blockWork, &c->routeWork, &c->compactWork, &c->shardWork, &c->shardSend, &c->shardRecv, &c->spillB, &c->tableView })
         if (b->ptr)
             (void)hipFree(b->ptr);
     if (c->ev0)

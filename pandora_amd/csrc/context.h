@@ -76,6 +76,7 @@ struct pgpu_ctx {
     DeviceBuffer work; // per-ray traversal state + queues, grown on demand
     DeviceBuffer blockWork; // scratch of the building-block entry points (work item -> bvh id)
     DeviceBuffer routeWork; // scratch of pgpu_trace_leaf_records
+    DeviceBuffer compactWork; // scratch of pgpu_compact_paths (flags, places, scan storage)
     unsigned long long* topCounters = nullptr; // SVDAG tests / culled of pgpu_top_episode calls (device)
 
     // several GPUs (sharded_abi.hip)

@@ -2,6 +2,7 @@
 // reference lines each step follows). HBM-bound streaming kernels: one ray per lane, SoA in, SoA out, no shared state
 // except the film's 64-bit integer atomics.
 #include "context.h"
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 
 #pragma clang fp contract(off)
@@ -226,6 +227,47 @@ __global__ __launch_bounds__(256) void splatMissesKernel(unsigned long long* fil
     }
 }
 
+// ---- pgpu_compact_paths: the paths that are still alive, in their order, at the front of another set of arrays
+__global__ __launch_bounds__(256) void liveFlagsKernel(const float* __restrict__ tnear, const float* __restrict__ tfar, uint32_t n, uint32_t* __restrict__ flags)
+{
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k <= n; k += gridDim.x * 256u)
+        flags[k] = (k < n && tnear[k] <= tfar[k]) ? 1u : 0u; // (one element more: the exclusive scan then also yields the total)
+}
+
+struct CompactArgs {
+    pgpu_rays in;
+    pgpu_paths pin;
+    pgpu_rays_out out;
+    pgpu_paths pout;
+    const uint32_t *flags, *places;
+    uint32_t n;
+};
+
+__global__ __launch_bounds__(256) void compactPathsKernel(CompactArgs a)
+{
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < a.n; k += gridDim.x * 256u) {
+        if (a.flags[k] == 0u)
+            continue;
+        const uint32_t d = a.places[k];
+        if (d >= a.n)
+            continue; // (cannot happen: places count the live rays before k)
+        a.out.ox[d] = a.in.ox[k];
+        a.out.oy[d] = a.in.oy[k];
+        a.out.oz[d] = a.in.oz[k];
+        a.out.dx[d] = a.in.dx[k];
+        a.out.dy[d] = a.in.dy[k];
+        a.out.dz[d] = a.in.dz[k];
+        a.out.tnear[d] = a.in.tnear[k];
+        a.out.tfar[d] = a.in.tfar[k];
+        a.pout.rng_state[d] = a.pin.rng_state[k];
+        a.pout.rng_inc[d] = a.pin.rng_inc[k];
+        a.pout.pixel[d] = a.pin.pixel[k];
+        a.pout.wr[d] = a.pin.wr[k];
+        a.pout.wg[d] = a.pin.wg[k];
+        a.pout.wb[d] = a.pin.wb[k];
+    }
+}
+
 uint32_t gridFor(const pgpu_ctx* c, size_t n) { return uint32_t(std::max<size_t>(1, std::min<size_t>((n + 255) / 256, size_t(c->numCUs) * 8))); }
 
 bool pathsOk(const pgpu_paths* p) { return p && p->rng_state && p->rng_inc && p->pixel && p->wr && p->wg && p->wb; }
@@ -319,6 +361,51 @@ int pgpu_splat_misses(pgpu_ctx* c, unsigned long long* film, size_t n_pixels, co
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
     hipLaunchKernelGGL(splatMissesKernel, dim3(gridFor(c, n)), dim3(256), 0, stream, film, uint32_t(n_pixels), obj, *paths, uint32_t(n), sky[0], sky[1], sky[2]);
     HIP_TRY(c, hipGetLastError());
+    return PGPU_OK;
+}
+int pgpu_compact_paths(pgpu_ctx* c, const pgpu_rays* rays_in, const pgpu_paths* paths_in, size_t n, const pgpu_rays_out* rays_out, const pgpu_paths* paths_out,
+    size_t* n_live, void* stream_)
+{
+    if (!c || !rays_in || !rays_in->ox || !rays_in->oy || !rays_in->oz || !rays_in->dx || !rays_in->dy || !rays_in->dz || !rays_in->tnear || !rays_in->tfar
+        || !pathsOk(paths_in) || !raysOutOk(rays_out) || !pathsOk(paths_out) || !n_live)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_compact_paths: null argument");
+    if (n > 0x3FFFFFFFull)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_compact_paths: batch too large");
+    if (rays_out->ox == rays_in->ox || paths_out->pixel == paths_in->pixel)
+        return fail(c, PGPU_ERR_INVALID, "pgpu_compact_paths: the output arrays must not be the input arrays");
+    *n_live = 0;
+    if (n == 0)
+        return PGPU_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : c->stream;
+    const size_t words = alignUp((n + 1) * 4);
+    size_t scanBytes = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), int(n) + 1, stream));
+    const int rc = ensure(c, c->compactWork, 2 * words + alignUp(scanBytes));
+    if (rc != PGPU_OK)
+        return rc;
+    unsigned char* base = static_cast<unsigned char*>(c->compactWork.ptr);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(base);
+    uint32_t* places = reinterpret_cast<uint32_t*>(base + words);
+    hipLaunchKernelGGL(liveFlagsKernel, dim3(gridFor(c, n + 1)), dim3(256), 0, stream, rays_in->tnear, rays_in->tfar, uint32_t(n), flags);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(base + 2 * words, scanBytes, flags, places, int(n) + 1, stream));
+    CompactArgs a {};
+    a.in = *rays_in;
+    a.pin = *paths_in;
+    a.out = *rays_out;
+    a.pout = *paths_out;
+    a.flags = flags;
+    a.places = places;
+    a.n = uint32_t(n);
+    hipLaunchKernelGGL(compactPathsKernel, dim3(gridFor(c, n)), dim3(256), 0, stream, a);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t live = 0;
+    HIP_TRY(c, hipMemcpyAsync(&live, places + n, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipStreamSynchronize(stream));
+    if (live > n)
+        return fail(c, PGPU_ERR_HIP, "pgpu_compact_paths: more live paths than paths (internal error)");
+    *n_live = live;
     return PGPU_OK;
 }
 }

@@ -137,3 +137,60 @@ def test_bounce_from_two_level_hits_and_missing_shading_data():
         _check_bounce(got, paths, want, want_paths, "two-level bounce")
     finally:
         ctx.close()
+
+
+def test_compacted_paths_are_the_live_ones_in_order_and_the_film_is_the_same():
+    """pgpu_compact_paths (the end of a path, path_integrator.cpp:109-127): after a bounce, the rays with tnear <= tfar and their
+    path states at the front of new arrays, in their order; a frame traced with the dead slots dropped after every bounce gives
+    the film of a frame that keeps them, integer for integer (a dead slot adds nothing), both layouts of the next trace included."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    dev = torch.device("cuda", 0)
+    mesh = pa.scenes.g_small()
+    tl = pa.accel.build_two_level(mesh.pos, mesh.idx, 64, svdag_res=16)
+    cam = pa.accel.make_camera((0, 1, 3.2), (0, 1, 0), (0, 1, 0), 50, 1.0)
+    side, spp = 96, 2
+    n = side * side * spp
+    sky, albedo = (0.9, 1.0, 1.3), (0.7, 0.5, 0.3)
+    ctx = pa.accel.Context(0)
+    try:
+        ctx.set_keep_shading(True)
+        tl.upload(ctx, ctx.upload_mesh(mesh.pos, mesh.idx))
+
+        def frame(compact):
+            film = torch.zeros((side * side, 3), dtype=torch.int64, device=dev)
+            rays, paths = ctx.camera_rays(cam, side, side, spp, 11, 0, n, dev)
+            traced = []
+            for depth in range(4):
+                hits, _ = ctx.trace(rays)
+                ctx.splat_misses(film, hits["obj"], paths, sky)
+                traced.append(int(rays.shape[1]))
+                if depth == 3 or rays.shape[1] == 0:
+                    break
+                rays = ctx.lambert_bounce(None, rays, hits, albedo, paths)
+                if compact:
+                    ctx.sync()
+                    before = _np(rays).copy()
+                    state = {k: _np(v).copy() for k, v in paths.items()}
+                    rays, paths = ctx.compact_paths(rays, paths)
+                    live = before[6] <= before[7]
+                    assert rays.shape[1] == int(live.sum())
+                    assert np.array_equal(_np(rays).view(np.uint32), before[:, live].view(np.uint32)), f"depth {depth}: rays"
+                    for k, v in state.items():
+                        assert np.array_equal(_np(paths[k]).view(np.uint8), np.ascontiguousarray(v[live]).view(np.uint8)), f"depth {depth}: {k}"  # (bit patterns: a weight may be NaN)
+            ctx.sync()
+            return _np(film).copy(), traced
+
+        kept, slots = frame(False)
+        dropped, live = frame(True)
+        assert slots == [n] * 4 and live[0] == n and live[1] < n and live[3] < live[1]
+        assert np.array_equal(kept, dropped) and np.count_nonzero(kept) > 100
+        with pytest.raises(pa.capi.PandoraError):  # in place is refused
+            rays, paths = ctx.camera_rays(cam, side, side, spp, 11, 0, n, dev)
+            r, _ = ctx._rays_struct(rays)
+            import ctypes as C
+            k = C.c_size_t(0)
+            pa.accel._check(ctx._L.pgpu_compact_paths(ctx._h, C.byref(r), C.byref(ctx._paths_struct(paths)), n, C.byref(r), C.byref(ctx._paths_struct(paths)), C.byref(k), 0), ctx._h)
+    finally:
+        ctx.close()
