@@ -530,8 +530,12 @@ class Context:
         assert rays.shape[0] == 8
         if self._is_torch(rays):
             # (rows may be the front of longer rows: what compact_paths returns)
-            assert rays.is_cuda and str(rays.dtype) == "torch.float32" and (n == 0 or rays.stride(1) == 1) and rays.stride(0) >= n
-            base, stride = rays.data_ptr(), int(rays.stride(0)) * 4
+            assert rays.is_cuda and str(rays.dtype) == "torch.float32"
+            if rays.is_contiguous():
+                base, stride = rays.data_ptr(), n * 4
+            else:
+                assert rays.stride(1) == 1 and rays.stride(0) >= n
+                base, stride = rays.data_ptr(), int(rays.stride(0)) * 4
         else:
             assert rays.dtype == np.float32 and rays.flags["C_CONTIGUOUS"]
             base, stride = rays.ctypes.data, n * 4
