@@ -390,3 +390,39 @@ def test_a_clustering_that_does_not_finish_leaves_the_build_to_the_radix_tree(ct
         assert np.array_equal(a.nodes.view(np.uint32), b.nodes.view(np.uint32)) and np.array_equal(a.leaf_idx, b.leaf_idx)
         differs += a.n_nodes != c.n_nodes or not np.array_equal(a.leaf_idx, c.leaf_idx)
     assert differs > 0  # (the clustered trees are other trees)
+
+
+@pytest.mark.parametrize("max_leaf", [1, 4])
+def test_random_groups_of_every_small_size(ctx, max_leaf):
+    """Groups of 1 ... 1000 triangles in random order, some made of copies of one triangle, some on a line: every group's tree has the
+    reference's layout; a group that fits a leaf is a root handle, any other has fewer nodes than triangles."""
+    rng = np.random.default_rng(17 + max_leaf)
+    sizes = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 33, 64, 100, 257, 1000] * 3
+    rng.shuffle(sizes)
+    n = int(sum(sizes))
+    pos = rng.uniform(-5, 5, (3 * n, 3)).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    for g, s in enumerate(sizes):
+        tri = slice(3 * starts[g], 3 * starts[g + 1])
+        pos[tri] = pos[tri] * 0.2 + rng.uniform(-20, 20, 3).astype(np.float32)  # (groups apart from each other)
+        if g % 5 == 1:
+            pos[tri] = np.tile(pos[3 * starts[g]:3 * starts[g] + 3], (s, 1))  # copies of one triangle
+        elif g % 5 == 2:
+            pos[tri, 1:] = pos[3 * starts[g], 1:]  # on a line
+    order = rng.permutation(n).astype(np.uint32)  # the groups name their triangles in no particular order
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    groups = [np.ascontiguousarray(order[np.sort(rank[starts[g]:starts[g + 1]])]) for g in range(len(sizes))]
+    for g in range(len(sizes)):
+        assert np.array_equal(np.sort(groups[g]), np.arange(starts[g], starts[g + 1]))
+    mesh = pa.scenes.Mesh(pos, idx)
+    bvhs, host_built = pa.accel.build_bvh8_device(ctx, pos, idx, groups, max_leaf=max_leaf)
+    assert host_built == 0
+    for hb, g, s in zip(bvhs, groups, sizes):
+        assert np.array_equal(hb.prim_ids, g)
+        depth = check_tree(hb, mesh, max_leaf)
+        if s <= max_leaf:
+            assert hb.n_nodes == 0 and depth == 0
+        elif s <= 8:
+            assert 1 <= hb.n_nodes < s and depth < s  # (boxes without surface -- copies, a line -- cost nothing either way: any valid shape)
